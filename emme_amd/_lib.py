@@ -1,0 +1,263 @@
+"""ctypes binding of include/emme_hip.h.  Names mirror the reference's objects:
+Params <- Parameters (include/Parameters.h), Context <- EigenSolver (include/solver.h:44-516).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class EmmeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[emme {code}] {msg}")
+        self.code = code
+        self.reason = msg
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "libemme_hip.so")
+
+
+class Params(C.Structure):
+    """emme_params_t (include/emme_params.h)."""
+
+    _fields_ = [
+        ("conf", C.c_int), ("iteration_method", C.c_int),
+        ("q", C.c_double), ("shat", C.c_double), ("tau", C.c_double),
+        ("epsilon_n", C.c_double), ("epsilon_r", C.c_double),
+        ("eta_i", C.c_double), ("eta_e", C.c_double), ("k_rho", C.c_double),
+        ("beta_e", C.c_double), ("R", C.c_double), ("vt", C.c_double),
+        ("omega_d_coeff", C.c_double), ("length", C.c_double), ("theta", C.c_double),
+        ("npoints", C.c_int), ("iteration_step_limit", C.c_int),
+        ("integration_precision", C.c_double), ("integration_accuracy", C.c_double),
+        ("integration_iteration_limit", C.c_int), ("integration_start_points", C.c_int),
+        ("arc_coeff", C.c_double),
+        ("water_bag_weight_vpara", C.c_double), ("water_bag_weight_vperp", C.c_double),
+        ("drift_center_transformation_switch", C.c_int),
+        ("iteration_precision", C.c_double),
+        ("initial_guess", C.c_double * 2),
+        ("eta_k", C.c_double), ("lh", C.c_int), ("mh", C.c_int),
+        ("epsilon_h_t", C.c_double), ("alpha_0", C.c_double), ("r_over_R", C.c_double),
+        ("b_theta", C.c_double), ("alpha", C.c_double), ("omega_s_i", C.c_double),
+        ("omega_s_e", C.c_double), ("omega_d_bar", C.c_double),
+        ("deltap", C.c_double), ("beta_e_p", C.c_double), ("rdeltapp", C.c_double),
+        ("curvature_aver", C.c_double), ("shat_coeff", C.c_double),
+    ]
+
+    @property
+    def dim(self) -> int:
+        return self.npoints if self.beta_e == 0.0 else 2 * self.npoints
+
+
+class Profile(C.Structure):
+    """emme_profile_t."""
+
+    _fields_ = [
+        ("assemble_ms", C.c_double), ("assemble_launches", C.c_long),
+        ("linstep_ms", C.c_double), ("linstep_launches", C.c_long),
+        ("other_ms", C.c_double), ("other_launches", C.c_long),
+        ("gk_intervals", C.c_longlong), ("integrand_evals", C.c_longlong),
+        ("matrices", C.c_longlong),
+    ]
+
+
+def load():
+    """Load libemme_hip.so or raise: the product path never falls back to a CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EmmeError(-3, f"{path} is missing: build it with __graft_entry__.build() "
+                            "(make -C emme_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(path)
+    P = C.c_void_p
+    PP = C.POINTER(Params)
+    lib.emme_last_error.restype = C.c_char_p
+    lib.emme_params_from_json.argtypes = [C.c_char_p, PP]
+    lib.emme_params_derive.argtypes = [PP]
+    lib.emme_tables.argtypes = [PP, P, P, P, P]
+    lib.emme_weight.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.emme_weight.restype = C.c_double
+    lib.emme_ctx_create.argtypes = [PP, C.c_int, C.POINTER(P)]
+    lib.emme_ctx_destroy.argtypes = [P]
+    lib.emme_ctx_destroy.restype = None
+    lib.emme_ctx_set_stream.argtypes = [P, P]
+    lib.emme_ctx_dim.argtypes = [P]
+    lib.emme_ctx_profile_enable.argtypes = [P, C.c_int]
+    lib.emme_ctx_profile_read.argtypes = [P, C.POINTER(Profile), C.c_int]
+    lib.emme_assemble_batch.argtypes = [P, P, C.c_int, P, P]
+    lib.emme_trace_solve_batch.argtypes = [P, C.c_int, C.c_int, P, P, P, P]
+    lib.emme_newton_step_batch.argtypes = [P, P, P, C.c_int, P, P, C.c_int, P]
+    lib.emme_solve_roots.argtypes = [P, P, C.c_int, C.c_double, C.c_int, P, P, P, P]
+    lib.emme_ctx_get_matrix.argtypes = [P, C.c_int, P]
+    _LIB = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise EmmeError(rc, load().emme_last_error().decode(errors="replace"))
+
+
+def _fnum(x) -> str:
+    if isinstance(x, bool):
+        return "true" if x else "false"
+    if isinstance(x, int):
+        return str(x)
+    s = repr(float(x))
+    if "e" in s:
+        m, e = s.split("e")
+        if "." not in m:
+            m += ".0"
+        return m + "e" + e
+    return s
+
+
+def json_text(d: dict) -> str:
+    """Serialise a dict so that the reference grammar (a number is a float only if it
+    contains '.') reads back the intended values."""
+    items = []
+    for k, v in d.items():
+        if isinstance(v, str):
+            items.append(f'"{k}": "{v}"')
+        elif isinstance(v, (list, tuple)):
+            items.append(f'"{k}": [' + ", ".join(_fnum(x) for x in v) + "]")
+        elif isinstance(v, dict):
+            items.append(f'"{k}": ' + json_text(v))
+        else:
+            items.append(f'"{k}": {_fnum(v)}')
+    return "{" + ", ".join(items) + "}"
+
+
+def params_from_json(text: str) -> Params:
+    """Parameters::generate on a JSON text (reference src/Parameters.cpp:10-66)."""
+    p = Params()
+    _check(load().emme_params_from_json(text.encode(), C.byref(p)))
+    return p
+
+
+def params_from_dict(d: dict) -> Params:
+    return params_from_json(json_text(d))
+
+
+def tables(p: Params):
+    n = p.npoints
+    eta, g, b = np.zeros(n), np.zeros(n), np.zeros(n)
+    dx = C.c_double(0)
+    _check(load().emme_tables(C.byref(p), eta.ctypes.data, g.ctypes.data, b.ctypes.data,
+                              C.addressof(dx)))
+    return eta, g, b, dx.value
+
+
+def weight(n, i, j) -> float:
+    return load().emme_weight(n, i, j)
+
+
+def _c128(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """One (device, parameter set): owns device tables and batch scratch."""
+
+    def __init__(self, params: Params, device: int = -1):
+        self.lib = load()
+        self.params = params
+        h = C.c_void_p()
+        _check(self.lib.emme_ctx_create(C.byref(params), device, C.byref(h)))
+        self.h = h
+        self.dim = self.lib.emme_ctx_dim(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.emme_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_handle: int):
+        _check(self.lib.emme_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def profile(self, on=True):
+        _check(self.lib.emme_ctx_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=False) -> Profile:
+        pr = Profile()
+        _check(self.lib.emme_ctx_profile_read(self.h, C.byref(pr), int(reset)))
+        return pr
+
+    # matrixAssembler (include/solver.h:417-515), batched over omega
+    def assemble(self, omegas, out_device_ptr: int | None = None, want_intervals=False):
+        w = _c128(np.atleast_1d(omegas))
+        nb = w.shape[0]
+        iv = np.zeros(nb, dtype=np.int64)
+        if out_device_ptr is None:
+            M = np.zeros((nb, self.dim, self.dim), dtype=np.complex128)
+            _check(self.lib.emme_assemble_batch(self.h, w.ctypes.data, nb, M.ctypes.data,
+                                                iv.ctypes.data))
+            return (M, iv) if want_intervals else M
+        _check(self.lib.emme_assemble_batch(self.h, w.ctypes.data, nb,
+                                            C.c_void_p(out_device_ptr), iv.ctypes.data))
+        return iv
+
+    def trace_solve(self, A, B):
+        A = _c128(A).copy()
+        B = _c128(B).copy()
+        if A.ndim == 2:
+            A, B = A[None], B[None]
+        nb, n, _ = A.shape
+        tr = np.zeros(nb, dtype=np.complex128)
+        info = np.zeros(nb, dtype=np.int32)
+        _check(self.lib.emme_trace_solve_batch(self.h, n, nb, A.ctypes.data, B.ctypes.data,
+                                               tr.ctypes.data, info.ctypes.data))
+        return tr, info
+
+    # newtonTraceSecantIteration (include/solver.h:113-160), batched
+    def newton_step(self, omegas, M, Mp, method=0):
+        w = _c128(np.atleast_1d(omegas)).copy()
+        nb = w.shape[0]
+        M = _c128(M, (nb, self.dim, self.dim)).copy()
+        Mp = _c128(Mp, (nb, self.dim, self.dim)).copy()
+        dw = np.zeros(nb, dtype=np.complex128)
+        info = np.zeros(nb, dtype=np.int32)
+        _check(self.lib.emme_newton_step_batch(self.h, w.ctypes.data, dw.ctypes.data, nb,
+                                               M.ctypes.data, Mp.ctypes.data, method,
+                                               info.ctypes.data))
+        return w, dw, M, Mp, info
+
+    # solve_once_eigen (src/main.cpp:19-80), batched over initial guesses
+    def solve_roots(self, guesses, tol=None, step_limit=None, want_iterates=False):
+        g = _c128(np.atleast_1d(guesses))
+        n = g.shape[0]
+        tol = self.params.iteration_precision if tol is None else tol
+        step_limit = self.params.iteration_step_limit if step_limit is None else step_limit
+        roots = np.zeros(n, dtype=np.complex128)
+        iters = np.zeros(n, dtype=np.int32)
+        info = np.zeros(n, dtype=np.int32)
+        its = np.zeros((n, step_limit + 1), dtype=np.complex128) if want_iterates else None
+        _check(self.lib.emme_solve_roots(self.h, g.ctypes.data, n, tol, step_limit,
+                                         roots.ctypes.data, iters.ctypes.data, info.ctypes.data,
+                                         its.ctypes.data if want_iterates else None))
+        return (roots, iters, info, its) if want_iterates else (roots, iters, info)
+
+    def final_matrix(self, b=0):
+        M = np.zeros((self.dim, self.dim), dtype=np.complex128)
+        _check(self.lib.emme_ctx_get_matrix(self.h, b, M.ctypes.data))
+        return M

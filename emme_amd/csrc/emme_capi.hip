@@ -1,0 +1,591 @@
+// emme_capi.hip -- implementation of the C ABI declared in include/emme_hip.h:
+// context (device tables, batch scratch, stream, profiling) and the batched drivers that
+// stand where the reference has EigenSolver's constructor / matrixAssembler /
+// newtonTraceSecantIteration (include/solver.h:396-415, 417-515, 113-160) and the
+// solve_once_eigen loop (src/main.cpp:19-80).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/emme_hip.h"
+#include "launch.hpp"
+
+namespace emme {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+namespace {
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));             \
+            return e_ == hipErrorOutOfMemory ? EMME_ENOMEM : EMME_EDEVICE;             \
+        }                                                                              \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice;
+}
+
+enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2 };
+
+}  // namespace
+}  // namespace emme
+
+using namespace emme;
+
+struct emme_ctx {
+    emme_params_t p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevParams P;
+    int N = 0, dim = 0, nm = 1, npairs = 0;
+    double* d_tab = nullptr;
+    ushort2* d_pairs = nullptr;
+    // batch scratch
+    int cap = 0;
+    double *d_omega = nullptr, *d_domega = nullptr, *d_tr = nullptr;
+    int *d_active = nullptr, *d_iters = nullptr, *d_info = nullptr, *d_status = nullptr;
+    unsigned long long* d_intervals = nullptr;
+    int mat_cap = 0;  // matrices per set
+    double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
+    double* d_iterates = nullptr;
+    size_t iterates_cap = 0;
+    int last_n = 0;
+    // profiling
+    bool prof = false;
+    emme_profile_t acc{};
+    struct Span {
+        int kind;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
+
+hipEvent_t get_event(emme_ctx* c) {
+    if (!c->free_events.empty()) {
+        hipEvent_t e = c->free_events.back();
+        c->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct ScopedSpan {
+    emme_ctx* c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedSpan(emme_ctx* ctx, int k) : c(ctx), kind(k) {
+        if (c->prof) {
+            a = get_event(c);
+            b = get_event(c);
+            if (a) (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~ScopedSpan() {
+        if (c->prof && a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->spans.push_back({kind, a, b});
+        }
+    }
+};
+
+int drain_spans(emme_ctx* c) {
+    for (auto& s : c->spans) {
+        HIP_TRY(hipEventSynchronize(s.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        if (s.kind == K_ASM)
+            c->acc.assemble_ms += ms, c->acc.assemble_launches++;
+        else if (s.kind == K_LIN)
+            c->acc.linstep_ms += ms, c->acc.linstep_launches++;
+        else
+            c->acc.other_ms += ms, c->acc.other_launches++;
+        c->free_events.push_back(s.a);
+        c->free_events.push_back(s.b);
+    }
+    c->spans.clear();
+    return EMME_OK;
+}
+
+int ensure_batch(emme_ctx* c, int nb) {
+    if (nb <= c->cap) return EMME_OK;
+    auto F = [](auto*& p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active), F(c->d_iters), F(c->d_info),
+        F(c->d_status), F(c->d_intervals);
+    c->cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->d_omega, sizeof(double) * 2 * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_domega, sizeof(double) * 2 * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_tr, sizeof(double) * 2 * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_active, sizeof(int) * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_iters, sizeof(int) * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_info, sizeof(int) * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(int) * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
+    c->cap = nb;
+    return EMME_OK;
+}
+
+// which matrix sets a call needs: bit0 M, bit1 Mold, bit2 Mp, bit3 work
+int ensure_mats(emme_ctx* c, int nb, int sets) {
+    if (nb > c->mat_cap) {
+        auto F = [](double*& p) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        };
+        F(c->d_M), F(c->d_Mold), F(c->d_Mp), F(c->d_work);
+        c->mat_cap = nb;
+    }
+    const size_t bytes = mat_doubles(c) * sizeof(double) * (size_t)c->mat_cap;
+    if ((sets & 1) && !c->d_M) HIP_TRY(hipMalloc((void**)&c->d_M, bytes));
+    if ((sets & 2) && !c->d_Mold) HIP_TRY(hipMalloc((void**)&c->d_Mold, bytes));
+    if ((sets & 4) && !c->d_Mp) HIP_TRY(hipMalloc((void**)&c->d_Mp, bytes));
+    if ((sets & 8) && !c->d_work) HIP_TRY(hipMalloc((void**)&c->d_work, bytes));
+    return EMME_OK;
+}
+
+int items_per_group_for(const emme_ctx* c, int nbatch) {
+    // enough lane groups to give every SIMD several waves, but a few integrals per group
+    // when the batch is large so the start-up cost (table staging) is amortised
+    const int gw = c->p.integration_start_points == 15 ? 16 : 32;
+    const long total = (long)c->npairs * c->nm * nbatch;
+    const long target_groups = 256L * 16 * (64 / gw) * 4;
+    long ipg = total / target_groups;
+    if (ipg < 1) ipg = 1;
+    if (ipg > 8) ipg = 8;
+    return (int)ipg;
+}
+
+int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active, double* d_M,
+                const double* d_Mold, double* d_Mp, const double* d_domega) {
+    AssembleLaunch L;
+    L.P = c->P;
+    L.gk_points = c->p.integration_start_points;
+    L.nbatch = nbatch;
+    L.npairs = c->npairs;
+    L.items_per_group = items_per_group_for(c, nbatch);
+    L.tab = c->d_tab;
+    L.pairs = c->d_pairs;
+    L.omega = d_omega;
+    L.active = d_active;
+    L.M = d_M;
+    L.Mold = d_Mold;
+    L.Mp = d_Mp;
+    L.domega = d_domega;
+    L.intervals = c->d_intervals;
+    L.status = c->d_status;
+    {
+        ScopedSpan s(c, K_ASM);
+        HIP_TRY(launch_assemble(L, c->stream));
+    }
+    c->acc.matrices += nbatch;  // upper bound when some items are inactive
+    return EMME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* emme_last_error(void) { return g_error.c_str(); }
+int emme_version(void) { return 1; }
+
+int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
+    if (!p || !out) return EMME_EINVAL;
+    *out = nullptr;
+    if (p->integration_start_points != 15 && p->integration_start_points != 31) {
+        // include/functions.h:329
+        set_error("integration_start_points should be 15 or 31");
+        return EMME_ECONFIG;
+    }
+    if (p->npoints < 2 || p->npoints > 65535) {
+        set_error("npoints must be in [2, 65535]");
+        return EMME_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (the MI355X path has no CPU fallback)");
+        return EMME_EDEVICE;
+    }
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950");
+        return EMME_EDEVICE;
+    }
+
+    emme_ctx* c = new emme_ctx;
+    c->p = *p;
+    c->device = device;
+    const int N = p->npoints;
+    c->N = N;
+    const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
+    c->dim = es ? N : 2 * N;
+    c->nm = es ? 1 : 3;
+
+    DevParams& P = c->P;
+    std::vector<double> tab(3 * (size_t)N);
+    double dx = 0;
+    emme_tables(p, tab.data(), tab.data() + N, tab.data() + 2 * N, &dx);
+    P.N = N, P.dim = c->dim, P.nm = c->nm, P.max_sub = p->integration_iteration_limit;
+    P.dx = dx;
+    P.inv_arc = 1.0 / p->arc_coeff;
+    P.qR = p->q * p->R;
+    P.vt = p->vt;
+    P.cb = (p->q * p->R) / p->vt * (p->omega_d_bar);                                  // :88
+    P.cbe = (p->q * p->R) / p->vt * (p->omega_d_bar * p->omega_s_e / p->omega_s_i);  // :93
+    P.omega_s_i = p->omega_s_i, P.omega_s_e = p->omega_s_e;
+    P.eta_i = p->eta_i, P.eta_e = p->eta_e, P.tau = p->tau;
+    P.rel_tol = p->integration_precision;
+    P.prec_goal = p->integration_accuracy;
+    P.pref = (p->q * p->R) / (p->vt * std::sqrt(2.0 * M_PI));
+    P.diag_a = 1.0 + 1.0 / p->tau;
+    P.diag_d = es ? 0.0 : (2.0 * p->tau) / p->beta_e;
+
+    // pair list ordered by diagonal offset (see assemble.hip header)
+    std::vector<ushort2> pairs;
+    pairs.reserve((size_t)N * (N - 1) / 2);
+    for (int off = 1; off < N; ++off)
+        for (int i = 0; i + off < N; ++i) pairs.push_back(make_ushort2((unsigned short)i, (unsigned short)(i + off)));
+    c->npairs = (int)pairs.size();
+
+    int rc = EMME_OK;
+    auto fail = [&](int code) {
+        emme_ctx_destroy(c);
+        return code;
+    };
+    if (hipMalloc((void**)&c->d_tab, tab.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_pairs, pairs.size() * sizeof(ushort2)) != hipSuccess) {
+        set_error("hipMalloc failed for tables");
+        return fail(EMME_ENOMEM);
+    }
+    if (hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_pairs, pairs.data(), pairs.size() * sizeof(ushort2), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("hipMemcpy failed for tables");
+        return fail(EMME_EDEVICE);
+    }
+    (void)rc;
+    *out = c;
+    return EMME_OK;
+}
+
+void emme_ctx_destroy(emme_ctx_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    else (void)hipDeviceSynchronize();
+    auto F = [](auto* p) {
+        if (p) (void)hipFree((void*)p);
+    };
+    F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
+        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_M), F(c->d_Mold),
+        F(c->d_Mp), F(c->d_work), F(c->d_iterates);
+    for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int emme_ctx_set_stream(emme_ctx_t* c, void* s) {
+    if (!c) return EMME_EINVAL;
+    c->stream = (hipStream_t)s;
+    return EMME_OK;
+}
+
+int emme_ctx_dim(const emme_ctx_t* c) { return c ? c->dim : EMME_EINVAL; }
+
+int emme_ctx_profile_enable(emme_ctx_t* c, int on) {
+    if (!c) return EMME_EINVAL;
+    c->prof = on != 0;
+    return EMME_OK;
+}
+
+int emme_ctx_profile_read(emme_ctx_t* c, emme_profile_t* out, int reset) {
+    if (!c || !out) return EMME_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_spans(c);
+    if (rc) return rc;
+    c->acc.integrand_evals = c->acc.gk_intervals * c->p.integration_start_points;
+    *out = c->acc;
+    if (reset) c->acc = emme_profile_t{};
+    return EMME_OK;
+}
+
+int emme_assemble_batch(emme_ctx_t* c, const double* omega, int nbatch, double* M,
+                        long long* intervals) {
+    if (!c || !omega || !M || nbatch < 1) return EMME_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_batch(c, nbatch);
+    if (rc) return rc;
+    const bool dev_out = is_device_ptr(M);
+    double* dM = M;
+    if (!dev_out) {
+        rc = ensure_mats(c, nbatch, 1);
+        if (rc) return rc;
+        dM = c->d_M;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_omega, omega, sizeof(double) * 2 * nbatch, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_intervals, 0, sizeof(unsigned long long) * nbatch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * nbatch, c->stream));
+    rc = do_assemble(c, nbatch, c->d_omega, nullptr, dM, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (!dev_out)
+        HIP_TRY(hipMemcpyAsync(M, dM, mat_doubles(c) * sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> iv(nbatch);
+    std::vector<int> stv(nbatch);
+    HIP_TRY(hipMemcpyAsync(iv.data(), c->d_intervals, sizeof(unsigned long long) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stv.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    bool bad = false;
+    for (int b = 0; b < nbatch; ++b) {
+        c->acc.gk_intervals += (long long)iv[b];
+        if (intervals) intervals[b] = (long long)iv[b];
+        bad |= stv[b] != 0;
+    }
+    if (bad) {
+        set_error("quadrature depth cap hit or non-finite integral in at least one item");
+        return EMME_ENUMERIC;
+    }
+    return EMME_OK;
+}
+
+int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* B, double* tr,
+                           int* info) {
+    if (!c || !A || !B || !tr || !info || n < 1 || nbatch < 1) return EMME_EINVAL;
+    if ((size_t)2 * n * sizeof(double2) > 64 * 1024) {
+        set_error("n too large for the LDS-staged pivot row");
+        return EMME_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_batch(c, nbatch);
+    if (rc) return rc;
+    const bool devA = is_device_ptr(A), devB = is_device_ptr(B);
+    if (devA != devB) {
+        set_error("A and B must both be host or both be device pointers");
+        return EMME_EINVAL;
+    }
+    const size_t bytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
+    double *dA = A, *dB = B;
+    if (!devA) {
+        HIP_TRY(hipMalloc((void**)&dA, bytes));
+        if (hipMalloc((void**)&dB, bytes) != hipSuccess) {
+            (void)hipFree(dA);
+            set_error("hipMalloc failed");
+            return EMME_ENOMEM;
+        }
+        HIP_TRY(hipMemcpyAsync(dA, A, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dB, B, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    {
+        ScopedSpan s(c, K_LIN);
+        HIP_TRY(launch_trace_solve(n, nbatch, dA, dB, nullptr, c->d_tr, c->d_info, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(tr, c->d_tr, sizeof(double) * 2 * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!devA) {
+        (void)hipFree(dA);
+        (void)hipFree(dB);
+    }
+    return EMME_OK;
+}
+
+int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nbatch, double* M,
+                           double* Mp, int method, int* info) {
+    if (!c || !omega || !domega || !M || !Mp || !info || nbatch < 1) return EMME_EINVAL;
+    if (method != EMME_METHOD_TRACE_SECANT) {
+        set_error("only iteration_method \"TraceSecant\" is implemented on the device");
+        return EMME_ECONFIG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_batch(c, nbatch);
+    if (rc) return rc;
+    const bool dev = is_device_ptr(M);
+    if (dev != is_device_ptr(Mp)) {
+        set_error("M and Mp must both be host or both be device pointers");
+        return EMME_EINVAL;
+    }
+    const size_t mbytes = mat_doubles(c) * sizeof(double) * nbatch;
+    rc = ensure_mats(c, nbatch, dev ? (2 | 8) : (1 | 2 | 4 | 8));
+    if (rc) return rc;
+    double *dM = M, *dMp = Mp;
+    if (!dev) {
+        dM = c->d_M, dMp = c->d_Mp;
+        HIP_TRY(hipMemcpyAsync(dM, M, mbytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dMp, Mp, mbytes, hipMemcpyHostToDevice, c->stream));
+    }
+    const hipMemcpyKind in_kind = is_device_ptr(omega) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out_kind = is_device_ptr(omega) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_TRY(hipMemcpyAsync(c->d_omega, omega, sizeof(double) * 2 * nbatch, in_kind, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_intervals, 0, sizeof(unsigned long long) * nbatch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * nbatch, c->stream));
+    {
+        // eigen_matrix_old = eigen_matrix (include/solver.h:114); the factorisation then
+        // consumes a scratch copy so M_old survives for the secant update
+        ScopedSpan s(c, K_OTHER);
+        HIP_TRY(hipMemcpyAsync(c->d_Mold, dM, mbytes, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_work, dM, mbytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    {
+        ScopedSpan s(c, K_LIN);
+        HIP_TRY(launch_trace_solve(c->dim, nbatch, c->d_work, dMp, nullptr, c->d_tr, c->d_info, c->stream));
+    }
+    {
+        ScopedSpan s(c, K_OTHER);
+        HIP_TRY(launch_newton_update(nbatch, c->d_tr, c->d_omega, c->d_domega, nullptr, nullptr,
+                                     c->d_info, 0.0, nullptr, 0, 0, c->stream));
+    }
+    rc = do_assemble(c, nbatch, c->d_omega, nullptr, dM, c->d_Mold, dMp, c->d_domega);
+    if (rc) return rc;
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(M, dM, mbytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(Mp, dMp, mbytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(omega, c->d_omega, sizeof(double) * 2 * nbatch, out_kind, c->stream));
+    HIP_TRY(hipMemcpyAsync(domega, c->d_domega, sizeof(double) * 2 * nbatch, out_kind, c->stream));
+    std::vector<unsigned long long> iv(nbatch);
+    HIP_TRY(hipMemcpyAsync(iv.data(), c->d_intervals, sizeof(unsigned long long) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    if (is_device_ptr(info))
+        HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToDevice, c->stream));
+    else
+        HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < nbatch; ++b) c->acc.gk_intervals += (long long)iv[b];
+    return EMME_OK;
+}
+
+int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, int step_limit,
+                     double* roots, int* iters, int* info, double* iterates) {
+    if (!c || !guesses || !roots || !iters || !info || n < 1 || step_limit < 0) return EMME_EINVAL;
+    if (c->p.iteration_method != EMME_METHOD_TRACE_SECANT) {
+        set_error("only iteration_method \"TraceSecant\" is implemented on the device");
+        return EMME_ECONFIG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_batch(c, n);
+    if (rc) return rc;
+    rc = ensure_mats(c, n, 1 | 2 | 4 | 8);
+    if (rc) return rc;
+    const int stride = step_limit + 1;
+    if (iterates) {
+        const size_t need = (size_t)n * stride * 2;
+        if (need > c->iterates_cap) {
+            if (c->d_iterates) (void)hipFree(c->d_iterates);
+            c->d_iterates = nullptr;
+            HIP_TRY(hipMalloc((void**)&c->d_iterates, need * sizeof(double)));
+            c->iterates_cap = need;
+        }
+        std::vector<double> nanv(need, std::numeric_limits<double>::quiet_NaN());
+        HIP_TRY(hipMemcpyAsync(c->d_iterates, nanv.data(), need * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const size_t mbytes = mat_doubles(c) * sizeof(double) * n;
+
+    // EigenSolver ctor (include/solver.h:396-415): eigen_value = 0.99 g, d = 0.01 g;
+    // M_old = M(eigen_value); eigen_value += d; M = M(eigen_value); M' = (M - M_old)/d
+    std::vector<double> w0(2 * (size_t)n), dw(2 * (size_t)n), w1(2 * (size_t)n);
+    for (int b = 0; b < 2 * n; ++b) {
+        w0[b] = 0.99 * guesses[b];
+        dw[b] = 0.01 * guesses[b];
+        w1[b] = w0[b] + dw[b];
+    }
+    std::vector<int> ones(n, 1), zeros(n, 0);
+    HIP_TRY(hipMemcpyAsync(c->d_active, ones.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_iters, zeros.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_info, zeros.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_intervals, 0, sizeof(unsigned long long) * n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * n, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_omega, w0.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_domega, dw.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    rc = do_assemble(c, n, c->d_omega, nullptr, c->d_Mold, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // w0 is reused as the staging buffer below
+    HIP_TRY(hipMemcpyAsync(c->d_omega, w1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    rc = do_assemble(c, n, c->d_omega, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
+    if (rc) return rc;
+
+    std::vector<int> act(n);
+    for (int j = 0; j <= step_limit; ++j) {  // src/main.cpp:43
+        {
+            ScopedSpan s(c, K_OTHER);
+            HIP_TRY(hipMemcpyAsync(c->d_Mold, c->d_M, mbytes, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_work, c->d_M, mbytes, hipMemcpyDeviceToDevice, c->stream));
+        }
+        {
+            ScopedSpan s(c, K_LIN);
+            HIP_TRY(launch_trace_solve(c->dim, n, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info, c->stream));
+        }
+        {
+            ScopedSpan s(c, K_OTHER);
+            HIP_TRY(launch_newton_update(n, c->d_tr, c->d_omega, c->d_domega, c->d_active, c->d_iters,
+                                         c->d_info, tol, c->d_iterates, j, stride, c->stream));
+        }
+        rc = do_assemble(c, n, c->d_omega, c->d_active, c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
+        if (rc) return rc;
+        {
+            ScopedSpan s(c, K_OTHER);
+            HIP_TRY(launch_retire(n, c->d_active, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(act.data(), c->d_active, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        bool any = false;
+        for (int b = 0; b < n; ++b) any |= act[b] != 0;
+        if (!any) break;
+    }
+    std::vector<unsigned long long> iv(n);
+    std::vector<int> stv(n);
+    HIP_TRY(hipMemcpyAsync(roots, c->d_omega, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(iters, c->d_iters, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(iv.data(), c->d_intervals, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(stv.data(), c->d_status, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (iterates)
+        HIP_TRY(hipMemcpyAsync(iterates, c->d_iterates, sizeof(double) * 2 * (size_t)n * stride, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_n = n;
+    bool bad = false;
+    for (int b = 0; b < n; ++b) {
+        c->acc.gk_intervals += (long long)iv[b];
+        bad |= stv[b] != 0;
+    }
+    if (bad) {
+        set_error("quadrature depth cap hit or non-finite integral in at least one item");
+        return EMME_ENUMERIC;
+    }
+    return EMME_OK;
+}
+
+int emme_ctx_get_matrix(emme_ctx_t* c, int b, double* M_host) {
+    if (!c || !M_host || b < 0 || b >= c->last_n || !c->d_M) return EMME_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(M_host, c->d_M + mat_doubles(c) * (size_t)b, mat_doubles(c) * sizeof(double), hipMemcpyDeviceToHost));
+    return EMME_OK;
+}
+
+}  // extern "C"

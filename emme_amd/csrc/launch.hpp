@@ -1,0 +1,46 @@
+// launch.hpp -- host-visible launch descriptors of the device kernels (internal to the .so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "emme_device.hpp"
+
+namespace emme {
+
+struct AssembleLaunch {
+    DevParams P;
+    int gk_points;       // 15 or 31
+    int nbatch;
+    int npairs;
+    int items_per_group; // scheduling knob: integrals handled per lane group
+    const double* tab;   // device: eta[N] | g[N] | b[N]
+    const void* pairs;   // device: ushort2[npairs]
+    const double* omega; // device: 2*nbatch
+    const int* active;   // device or null
+    double* M;           // device
+    const double* Mold;  // device or null
+    double* Mp;          // device or null
+    const double* domega; // device (needed when Mold != null)
+    unsigned long long* intervals;  // device or null
+    int* status;         // device
+};
+hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream);
+
+// tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
+hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
+                              double* tr /*2*nbatch*/, int* info, hipStream_t stream);
+
+// domega = -1/tr; omega += domega; iters += 1; active = !(|domega| < tol |omega|) && info == 0
+// (include/solver.h:139-140, src/main.cpp:53-56). `iterates` (nullable) records omega.
+hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,
+                                int* active, int* iters, const int* info, double tol,
+                                double* iterates, int iter_index, int iter_stride,
+                                hipStream_t stream);
+
+// active == 2 ("converged, last step done") -> 0
+hipError_t launch_retire(int nbatch, int* active, hipStream_t stream);
+
+// Mp = (M - Mold) / domega, elementwise (include/solver.h:54-57), for active items.
+hipError_t launch_secant(int nbatch, size_t nn, const double* M, const double* Mold,
+                         const double* domega, const int* active, double* Mp, hipStream_t stream);
+
+}  // namespace emme

@@ -1,0 +1,240 @@
+// linstep.hip -- the Newton linear step of the eigenvalue search, batched over omega.
+//
+// The reference calls LAPACK zsysv with n right-hand sides and then uses only
+// trace(M^-1 M') (include/solver.h:134-140).  Here each batch item is one workgroup that
+// runs a partial-pivot Gaussian elimination on the augmented system [M | M'] (the
+// pivoting / row-update scheme of the reference's own LU, src/solver.cpp:14-85) and then a
+// *truncated* back substitution: X(c,c) only needs rows c..n-1 of column c, which cuts the
+// triangular solve from n^3/2 to n^3/6 complex multiply-adds.
+//
+// Data stay in global memory (L2 / Infinity-Cache resident for the batch); the pivot row
+// and the current solution row are staged in LDS each step so that the rank-1 update reads
+// them at LDS rate and streams its own rows with coalesced 16-byte accesses.
+#include <hip/hip_runtime.h>
+
+#include "emme_device.hpp"
+#include "launch.hpp"
+
+namespace emme {
+
+namespace {
+
+constexpr int LU_THREADS = 1024;
+constexpr int LU_WAVES = LU_THREADS / 64;
+
+__device__ __forceinline__ cd ld(const double2* p) {
+    const double2 v = *p;
+    return mk(v.x, v.y);
+}
+__device__ __forceinline__ void st(double2* p, cd v) { *p = make_double2(v.x, v.y); }
+
+__global__ __launch_bounds__(LU_THREADS) void k_trace_solve(int n, double2* A, double2* B,
+                                                           const int* active, double2* tr_out,
+                                                           int* info_out) {
+    extern __shared__ double2 lds_row[];  // 2n entries: pivot row of [A | B], later x row
+    __shared__ double s_val[LU_WAVES];
+    __shared__ int s_idx[LU_WAVES];
+    __shared__ int s_piv;
+    __shared__ int s_info;
+    __shared__ double s_tr[2];
+
+    const int b = blockIdx.x;
+    if (active && active[b] == 0) return;
+    double2* a = A + (size_t)b * n * n;
+    double2* bb = B + (size_t)b * n * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid == 0) s_info = 0, s_tr[0] = 0.0, s_tr[1] = 0.0;
+    __syncthreads();
+
+    // ---- forward elimination with partial pivoting on [A | B] --------------------
+    for (int k = 0; k < n; ++k) {
+        // pivot = first row of maximal modulus in column k, rows k..n-1
+        double best = -1.0;
+        int brow = n;
+        for (int r = k + tid; r < n; r += LU_THREADS) {
+            const double v = norm2(ld(&a[(size_t)r * n + k]));
+            if (v > best) best = v, brow = r;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(brow, off);
+            if (ov > best || (ov == best && oi < brow)) best = ov, brow = oi;
+        }
+        if (lane == 0) s_val[wave] = best, s_idx[wave] = brow;
+        __syncthreads();
+        if (tid == 0) {
+            double bv = s_val[0];
+            int bi = s_idx[0];
+            for (int w = 1; w < LU_WAVES; ++w)
+                if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) bv = s_val[w], bi = s_idx[w];
+            // exactly singular (or NaN) column: LAPACK-style info = k+1, first occurrence
+            if (!(bv > 0.0)) {
+                if (s_info == 0) s_info = k + 1;
+                bi = -1;
+            }
+            s_piv = bi;
+        }
+        __syncthreads();
+        const int piv = s_piv;
+        if (piv < 0) continue;  // uniform: nothing to eliminate with
+
+        // swap rows k <-> piv over the columns still in play and stage the pivot row in LDS
+        for (int c = tid; c < 2 * n; c += LU_THREADS) {
+            if (c < n) {
+                if (c < k) continue;
+                const cd pv = ld(&a[(size_t)piv * n + c]);
+                if (piv != k) {
+                    const cd top = ld(&a[(size_t)k * n + c]);
+                    st(&a[(size_t)k * n + c], pv);
+                    st(&a[(size_t)piv * n + c], top);
+                }
+                lds_row[c] = make_double2(pv.x, pv.y);
+            } else {
+                const int cc = c - n;
+                const cd pv = ld(&bb[(size_t)piv * n + cc]);
+                if (piv != k) {
+                    const cd top = ld(&bb[(size_t)k * n + cc]);
+                    st(&bb[(size_t)k * n + cc], pv);
+                    st(&bb[(size_t)piv * n + cc], top);
+                }
+                lds_row[c] = make_double2(pv.x, pv.y);
+            }
+        }
+        __syncthreads();
+
+        const cd rp = rcp(mk(lds_row[k].x, lds_row[k].y));
+        for (int r = k + 1 + wave; r < n; r += LU_WAVES) {
+            const cd f = ld(&a[(size_t)r * n + k]) * rp;  // factor = A(r,k)/A(k,k)
+            if (f.x == 0.0 && f.y == 0.0) continue;
+            double2* ar = a + (size_t)r * n;
+            double2* br = bb + (size_t)r * n;
+            for (int c = k + 1 + lane; c < n; c += 64) {
+                const double2 p = lds_row[c];
+                st(&ar[c], ld(&ar[c]) - f * mk(p.x, p.y));
+            }
+            for (int c = lane; c < n; c += 64) {
+                const double2 p = lds_row[n + c];
+                st(&br[c], ld(&br[c]) - f * mk(p.x, p.y));
+            }
+        }
+        __syncthreads();
+    }
+
+    if (s_info != 0) {
+        if (tid == 0) {
+            tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
+            info_out[b] = s_info;
+        }
+        return;
+    }
+
+    // ---- truncated back substitution: X(c,c) needs only rows c..n-1 of column c ----
+    for (int r = n - 1; r >= 0; --r) {
+        const cd ru = rcp(ld(&a[(size_t)r * n + r]));
+        for (int c = tid; c <= r; c += LU_THREADS) {
+            const cd x = ld(&bb[(size_t)r * n + c]) * ru;
+            lds_row[c] = make_double2(x.x, x.y);
+            if (c == r) s_tr[0] += x.x, s_tr[1] += x.y;  // one thread per step
+        }
+        __syncthreads();
+        for (int rr = wave; rr < r; rr += LU_WAVES) {
+            const cd u = ld(&a[(size_t)rr * n + r]);
+            double2* brr = bb + (size_t)rr * n;
+            for (int c = lane; c <= rr; c += 64) {
+                const double2 x = lds_row[c];
+                st(&brr[c], ld(&brr[c]) - u * mk(x.x, x.y));
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        tr_out[b] = make_double2(s_tr[0], s_tr[1]);
+        info_out[b] = 0;
+    }
+}
+
+__global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, double2* domega,
+                                int* active, int* iters, const int* info, double tol,
+                                double2* iterates, int iter_index, int iter_stride) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbatch) return;
+    if (active && active[b] == 0) return;
+    // d_eigen_value = -1 / trace; eigen_value += d (include/solver.h:139-140)
+    const cd t = mk(tr[b].x, tr[b].y);
+    const cd d = -rcp(t);
+    cd w = mk(omega[b].x, omega[b].y);
+    w = w + d;
+    omega[b] = make_double2(w.x, w.y);
+    domega[b] = make_double2(d.x, d.y);
+    if (iters) iters[b] += 1;
+    if (iterates) iterates[(size_t)b * iter_stride + iter_index] = make_double2(w.x, w.y);
+    if (active) {
+        // stop when |d| < |tol * omega| (src/main.cpp:53-56) or on a failed factorisation.
+        // The reassembly at the new omega still happens this step (solver.h:157), so the
+        // flag only takes effect from the next step on: encoded as 2 = "last step".
+        const bool conv = hypot(d.x, d.y) < hypot(tol * w.x, tol * w.y);
+        const bool fail = info && info[b] != 0;
+        if (fail)
+            active[b] = 0;
+        else if (conv || !(isfinite(w.x) && isfinite(w.y)))
+            active[b] = 2;
+    }
+}
+
+__global__ void k_retire(int nbatch, int* active) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbatch && active[b] == 2) active[b] = 0;
+}
+
+__global__ void k_secant(size_t nn, const double2* M, const double2* Mold, const double2* domega,
+                         const int* active, double2* Mp) {
+    const int b = blockIdx.y;
+    if (active && active[b] == 0) return;
+    const cd rdw = rcp(mk(domega[b].x, domega[b].y));
+    const size_t base = (size_t)b * nn;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < nn;
+         k += (size_t)gridDim.x * blockDim.x) {
+        const double2 m = M[base + k], o = Mold[base + k];
+        const cd d = mk(m.x - o.x, m.y - o.y) * rdw;
+        Mp[base + k] = make_double2(d.x, d.y);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
+                              double* tr, int* info, hipStream_t stream) {
+    const size_t lds = (size_t)2 * n * sizeof(double2);
+    hipLaunchKernelGGL(k_trace_solve, dim3(nbatch), dim3(LU_THREADS), lds, stream, n,
+                       (double2*)A, (double2*)B, active, (double2*)tr, info);
+    return hipGetLastError();
+}
+
+hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,
+                                int* active, int* iters, const int* info, double tol,
+                                double* iterates, int iter_index, int iter_stride,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(k_newton_update, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch,
+                       (const double2*)tr, (double2*)omega, (double2*)domega, active, iters, info,
+                       tol, (double2*)iterates, iter_index, iter_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_retire(int nbatch, int* active, hipStream_t stream) {
+    hipLaunchKernelGGL(k_retire, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch, active);
+    return hipGetLastError();
+}
+
+hipError_t launch_secant(int nbatch, size_t nn, const double* M, const double* Mold,
+                         const double* domega, const int* active, double* Mp,
+                         hipStream_t stream) {
+    unsigned gx = (unsigned)((nn + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_secant, dim3(gx, nbatch), dim3(256), 0, stream, nn, (const double2*)M,
+                       (const double2*)Mold, (const double2*)domega, active, (double2*)Mp);
+    return hipGetLastError();
+}
+
+}  // namespace emme

@@ -1,0 +1,120 @@
+/* emme_hip.h -- C ABI of the MI355X (gfx950) dispersion-matrix assembly + eigenvalue
+ * search.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * The reference (ssskkkky/EMME) has no FFI; these entry points sit behind its two
+ * de-facto operator seams and its solve-once driver:
+ *
+ *   emme_params_from_json   <- util::json::parse + Parameters::generate
+ *                              (reference src/JsonParser.cpp:655-669, src/Parameters.cpp:10-66)
+ *   emme_assemble_batch     <- EigenSolver<T>::matrixAssembler(matrix_type&)
+ *                              (reference include/solver.h:417-515), batched over omega
+ *   emme_newton_step_batch  <- EigenSolver<T>::newtonTraceSecantIteration()
+ *                              (reference include/solver.h:113-160; LAPACK_zsysv call :134-136)
+ *   emme_solve_roots        <- solve_once_eigen loop (reference src/main.cpp:19-80) +
+ *                              EigenSolver ctor (include/solver.h:396-415), batched over guesses
+ *
+ * Conventions: every function returns 0 on success or a negative EMME_E* code (never
+ * throws); emme_last_error() gives the text for the calling thread.  Per-item `info`
+ * follows LAPACK: 0 ok, k>0 = factor U(k,k) exactly zero (include/solver.h:142-153).
+ * Complex numbers are interleaved (re,im) doubles == std::complex<double> == the layout
+ * of the reference's Matrix<std::complex<double>> (row-major, include/Matrix.h:43).
+ * Buffers are caller-owned and may be host or device pointers (detected with
+ * hipPointerGetAttributes); the context owns all device scratch.  Calls on one context
+ * must be serialised by the caller; different contexts are independent.
+ */
+#ifndef EMME_HIP_H
+#define EMME_HIP_H
+
+#include <stddef.h>
+
+#include "emme_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMME_OK 0
+#define EMME_EINVAL (-1)   /* bad argument                                        */
+#define EMME_EJSON (-2)    /* JSON syntax error / missing key / wrong type        */
+#define EMME_EDEVICE (-3)  /* no gfx950 device / HIP runtime failure              */
+#define EMME_ENOMEM (-4)   /* device or host allocation failed                    */
+#define EMME_ECONFIG (-5)  /* unsupported configuration (e.g. start points != 15|31) */
+#define EMME_ENUMERIC (-6) /* quadrature depth cap hit or non-finite result       */
+
+typedef struct emme_ctx emme_ctx_t;
+
+/* Per-kernel device timing, filled when profiling is enabled (hipEvents recorded on the
+ * context's stream around every launch). */
+typedef struct emme_profile {
+    double assemble_ms;       /* total time in the assembly kernel                  */
+    long assemble_launches;
+    double linstep_ms;        /* total time in the LU + trace kernel                */
+    long linstep_launches;
+    double other_ms;          /* copies / elementwise kernels                       */
+    long other_launches;
+    long long gk_intervals;   /* Gauss-Kronrod intervals evaluated (all launches)    */
+    long long integrand_evals; /* = intervals * integration_start_points             */
+    long long matrices;       /* matrices assembled                                  */
+} emme_profile_t;
+
+const char* emme_last_error(void);
+int emme_params_sizeof(void);
+int emme_version(void);
+
+/* JSON text -> raw + derived parameters.  Reproduces the reference parser's grammar
+ * (a number token is a float only if it contains '.', else atoi; no string escapes)
+ * and its "Failed to accessing key: <k>" errors.  Scan objects {head,step,tail} are
+ * replaced by their head (reference src/main.cpp:174-180). */
+int emme_params_from_json(const char* json_text, emme_params_t* out);
+/* Fill derived members from raw ones (reference src/Parameters.cpp:36-66, 211-223). */
+int emme_params_derive(emme_params_t* p);
+
+/* Host-side tables exactly as the device uses them (for tests / tooling):
+ * eta[N], g[N] = g_integration_f(eta), b[N] = bi(eta); returns dx in *dx. */
+int emme_tables(const emme_params_t* p, double* eta, double* g, double* b, double* dx);
+/* SingularityHandler weight W(i,j) (reference src/singularity_handler.cpp:3-24). */
+double emme_weight(int n, int i, int j);
+
+/* One context per (device, parameter set). device < 0 => current device. */
+int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out);
+void emme_ctx_destroy(emme_ctx_t* ctx);
+/* Launch everything on this hipStream_t (e.g. torch's current stream). NULL = default. */
+int emme_ctx_set_stream(emme_ctx_t* ctx, void* hip_stream);
+int emme_ctx_dim(const emme_ctx_t* ctx); /* N if beta_e == 0 else 2N */
+int emme_ctx_profile_enable(emme_ctx_t* ctx, int on);
+int emme_ctx_profile_read(emme_ctx_t* ctx, emme_profile_t* out, int reset);
+
+/* Fill M(omega_b) for b < nbatch.  omega: 2*nbatch doubles (host).  M: nbatch*dim*dim
+ * complex, row-major, host or device.  intervals (optional, host, nbatch long long):
+ * GK intervals evaluated per item. */
+int emme_assemble_batch(emme_ctx_t* ctx, const double* omega, int nbatch, double* M,
+                        long long* intervals);
+
+/* One trace-secant Newton step per item, in place (all arrays host or device, but
+ * consistently one of the two):
+ *   in : omega[b], M[b] = M(omega[b]), Mp[b] = M'(omega[b])
+ *   out: domega[b] = -1/tr(M^-1 M'), omega[b] += domega[b], M[b] = M(new omega),
+ *        Mp[b] = (M_new - M_old)/domega, info[b] (LAPACK convention).
+ * method must be EMME_METHOD_TRACE_SECANT (QR-secant: EMME_ECONFIG). */
+int emme_newton_step_batch(emme_ctx_t* ctx, double* omega, double* domega, int nbatch,
+                           double* M, double* Mp, int method, int* info);
+
+/* tr(A_b^-1 B_b) for b < nbatch by partial-pivot LU (A, B: nbatch*n*n complex, destroyed;
+ * host or device).  tr: 2*nbatch doubles (host). info: nbatch ints (host). */
+int emme_trace_solve_batch(emme_ctx_t* ctx, int n, int nbatch, double* A, double* B, double* tr,
+                           int* info);
+
+/* Batched root search: for each guess g_b run the reference's solve-once sequence
+ * (omega=0.99 g; M_old=M(omega); omega+=0.01 g; M; M'; then up to step_limit+1 Newton
+ * steps, stopping when |domega| < tol*|omega|).  All arrays host.
+ * roots: 2n doubles; iters: n ints (Newton steps done); info: n ints.
+ * iterates (optional): n*(step_limit+1)*2 doubles, omega after every step, NaN padded. */
+int emme_solve_roots(emme_ctx_t* ctx, const double* guesses, int n, double tol, int step_limit,
+                     double* roots, int* iters, int* info, double* iterates);
+/* Copy M(omega_final) of item b of the last emme_solve_roots call (dim*dim complex). */
+int emme_ctx_get_matrix(emme_ctx_t* ctx, int b, double* M_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMME_HIP_H */
