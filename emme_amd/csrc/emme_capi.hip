@@ -569,14 +569,12 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         HIP_TRY(hipMemcpyAsync(iterates, c->d_iterates, sizeof(double) * 2 * (size_t)n * stride, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->last_n = n;
-    bool bad = false;
     for (int b = 0; b < n; ++b) {
         c->acc.gk_intervals += (long long)iv[b];
-        bad |= stv[b] != 0;
-    }
-    if (bad) {
-        set_error("quadrature depth cap hit or non-finite integral in at least one item");
-        return EMME_ENUMERIC;
+        // a chain that met a non-finite integral or the quadrature depth cap is reported
+        // per item (the reference would carry the NaN to its "eigenvalue": "NaN" record,
+        // src/main.cpp:311-316); the other chains of the batch are unaffected
+        if (stv[b] != 0 && info[b] == 0) info[b] = EMME_ENUMERIC;
     }
     return EMME_OK;
 }

@@ -107,7 +107,8 @@ int emme_trace_solve_batch(emme_ctx_t* ctx, int n, int nbatch, double* A, double
 /* Batched root search: for each guess g_b run the reference's solve-once sequence
  * (omega=0.99 g; M_old=M(omega); omega+=0.01 g; M; M'; then up to step_limit+1 Newton
  * steps, stopping when |domega| < tol*|omega|).  All arrays host.
- * roots: 2n doubles; iters: n ints (Newton steps done); info: n ints.
+ * roots: 2n doubles; iters: n ints (Newton steps done); info: n ints (0 ok, k>0 singular
+ * pivot k, EMME_ENUMERIC if that chain met a non-finite integral / the depth cap).
  * iterates (optional): n*(step_limit+1)*2 doubles, omega after every step, NaN padded. */
 int emme_solve_roots(emme_ctx_t* ctx, const double* guesses, int n, double tol, int step_limit,
                      double* roots, int* iters, int* info, double* iterates);
