@@ -1,0 +1,135 @@
+"""Host layer of the product (JSON reader, parameter derivation, tables, C ABI surface).
+No GPU needed; no compute entry point is called."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle.binding import Params as OracleParams
+from oracle.binding import example_stellarator, example_tokamak
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(emme):
+    lib = emme.load()
+    hdr = open(os.path.join(ROOT, "include", "emme_hip.h")).read()
+    names = set(re.findall(r"\b(emme_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 18
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/emme_hip.h but not exported"
+
+
+def test_params_struct_layout_matches(emme, oracle):
+    assert emme.load().emme_params_sizeof() == ctypes.sizeof(emme.Params) == ctypes.sizeof(OracleParams)
+    assert [f[0] for f in emme.Params._fields_] == [f[0] for f in OracleParams._fields_]
+
+
+@pytest.mark.parametrize("make", [lambda: example_tokamak(npoints=40),
+                                  lambda: example_stellarator(npoints=20),
+                                  lambda: example_tokamak(npoints=16, conf="cylinder"),
+                                  lambda: example_tokamak(npoints=16, conf="taloyMagneticDrift", beta_e=0.003),
+                                  lambda: example_tokamak(npoints=16, conf="cylinder old")])
+def test_params_and_tables_equal_oracle(emme, oracle, make):
+    d = make()
+    p = emme.params_from_dict(d)
+    po = oracle.params(d)
+    for name, _ in emme.Params._fields_:
+        a, b = getattr(p, name), getattr(po, name)
+        if name == "initial_guess":
+            a, b = list(a), list(b)
+        assert a == b, name
+    eta, g, b, dx = emme.tables(p)
+    eo, dxo = oracle.grid(po.length, po.npoints)
+    assert np.array_equal(eta, eo) and dx == dxo
+    assert np.array_equal(g, [oracle.g(po, e) for e in eta])
+    assert np.array_equal(b, [oracle.bi(po, e) for e in eta])
+    n = p.npoints
+    assert all(emme.weight(n, i, j) == oracle.lib.oracle_weight(n, i, j)
+               for i in range(n) for j in range(n))
+
+
+def test_tables_against_golden_reference_values(emme):
+    f = np.load(os.path.join(G, "geometry.npz"), allow_pickle=False)
+    meta = json.load(open(os.path.join(G, "inputs.json")))
+    for name, d in meta["inputs"].items():
+        p = emme.params_from_dict(d)
+        want = dict(zip(meta["param_names"], f[name + "_params"]))
+        for k, v in want.items():
+            got = getattr(p, k) if k != "b_theta" else p.b_theta
+            assert got == v, (name, k)
+        eta, g, b, _ = emme.tables(p)
+        assert np.array_equal(eta, f[name + "_eta"]) and np.array_equal(b, f[name + "_b"])
+        if name == "stellarator":
+            assert np.abs(g - f[name + "_g"]).max() <= 2e-13 * np.abs(f[name + "_g"]).max()
+        else:
+            assert np.array_equal(g, f[name + "_g"])
+
+
+def test_parser_quirks_match_reference(emme):
+    """`1e-6` has no '.', so the reference lexes an INTEGER and atoi gives 1; `48.0` is a
+    float narrowed to int; `1.e2` and `-.25` are accepted floats (src/JsonParser.cpp:436-446)."""
+    q = json.load(open(os.path.join(G, "parser_quirks.json")))
+    p = emme.params_from_json(q["text"])
+    for k, v in q["expected"].items():
+        assert getattr(p, k) == v, k
+    assert p.integration_precision == 1.0 and p.npoints == 48 and p.arc_coeff == 100.0 and p.theta == -0.25
+
+
+def test_parser_errors_mirror_reference_texts(emme):
+    d = example_tokamak()
+    for missing, first in [("q", "q"), ("iteration_precision", "iteration_precision"),
+                           ("drift_center_transformation_switch", "drift_center_transformation_switch"),
+                           ("iteration_method", "iteration_method")]:
+        dd = {k: v for k, v in d.items() if k != missing}
+        with pytest.raises(emme.EmmeError) as e:
+            emme.params_from_dict(dd)
+        assert e.value.code == -2 and e.value.reason == f"Failed to accessing key: {first}"
+    # the shipped stellarator example lacks 7 keys; the first one the reference trips on
+    # inside Parameters is epsilon_r (`method` is read by main(), not here)
+    st = {k: v for k, v in example_stellarator().items()
+          if k not in ("method", "iteration_method", "epsilon_r", "omega_d_coeff",
+                       "water_bag_weight_vpara", "water_bag_weight_vperp",
+                       "drift_center_transformation_switch")}
+    with pytest.raises(emme.EmmeError) as e:
+        emme.params_from_dict(st)
+    assert e.value.reason == "Failed to accessing key: epsilon_r"
+    with pytest.raises(emme.EmmeError) as e:
+        emme.params_from_dict(dict(d, conf="tokamac"))
+    assert e.value.reason == "Input configuration not supported yet."
+    with pytest.raises(emme.EmmeError) as e:
+        emme.params_from_dict(dict(d, q="one"))
+    assert "Incorrect JSON type" in e.value.reason
+    with pytest.raises(emme.EmmeError) as e:
+        emme.params_from_json('{"conf": "tokamak", }')
+    assert "error: unexpected content" in e.value.reason
+
+
+def test_scan_object_stands_for_its_head(emme):
+    d = example_tokamak(omega_d_coeff={"head": 1.01, "tail": [0.01, 1.01], "step": 0.1})
+    assert emme.params_from_dict(d).omega_d_coeff == 1.01
+
+
+def test_duplicate_key_first_wins_and_no_escapes(emme):
+    t = emme.json_text(example_tokamak()).replace('"q": 1.4', '"q": 1.4, "q": 9.9')
+    assert emme.params_from_json(t).q == 1.4
+
+
+def test_compute_fails_loudly_without_gpu(emme):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(emme.EmmeError) as e:
+        emme.Context(emme.params_from_dict(example_tokamak()))
+    assert e.value.code == -3 and "no CPU fallback" in e.value.reason
+
+
+def test_unsupported_start_points_rejected(emme):
+    p = emme.params_from_dict(example_tokamak(integration_start_points=21))
+    with pytest.raises(emme.EmmeError) as e:
+        emme.Context(p)
+    assert e.value.reason == "integration_start_points should be 15 or 31"
