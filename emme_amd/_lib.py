@@ -20,7 +20,8 @@ class EmmeError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "libemme_hip.so")
+    # EMME_LIB lets a developer A/B a differently-built library; the default is the in-tree one
+    return os.environ.get("EMME_LIB") or os.path.join(HERE, "libemme_hip.so")
 
 
 class Params(C.Structure):

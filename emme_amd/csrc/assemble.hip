@@ -14,99 +14,12 @@
 // constant along a diagonal).
 #include <hip/hip_runtime.h>
 
-#include "emme_device.hpp"
+#include "assemble_common.hpp"
 #include "launch.hpp"
 
 namespace emme {
 
 namespace {
-
-// per-lane node tables: lane r of a group -> (signed abscissa, Kronrod weight, Gauss weight)
-__device__ const double kX15[8] = {0.,
-                                   0.20778495500789847,
-                                   0.40584515137739717,
-                                   0.58608723546769113,
-                                   0.74153118559939444,
-                                   0.86486442335976907,
-                                   0.94910791234275852,
-                                   0.99145537112081264};
-__device__ const double kWg15[4] = {0.41795918367346939, 0.38183005050511894,
-                                    0.27970539148927667, 0.12948496616886969};
-__device__ const double kWk15[8] = {2.09482141084727828e-01, 2.04432940075298892e-01,
-                                    1.90350578064785410e-01, 1.69004726639267903e-01,
-                                    1.40653259715525919e-01, 1.04790010322250184e-01,
-                                    6.30920926299785533e-02, 2.29353220105292250e-02};
-__device__ const double kX31[16] = {0.0,
-                                    0.1011420669187175,
-                                    0.20119409399743452,
-                                    0.29918000715316881,
-                                    0.39415134707756337,
-                                    0.48508186364023968,
-                                    0.57097217260853885,
-                                    0.65099674129741697,
-                                    0.72441773136017005,
-                                    0.79041850144246593,
-                                    0.84820658341042722,
-                                    0.8972645323440819,
-                                    0.9372733924007059,
-                                    0.96773907567913913,
-                                    0.98799251802048543,
-                                    0.99800229869339706};
-__device__ const double kWg31[8] = {0.20257824192556112, 0.19843148532711152,
-                                    0.18616100001556193, 0.1662692058169939,
-                                    0.1395706779261542,  0.10715922046717143,
-                                    0.07036604748810768, 0.030753241996119};
-__device__ const double kWk31[16] = {
-    0.10133000701479155,   0.100769845523875595,  0.099173598721791959,  0.0966427269836236785,
-    0.093126598170825321,  0.0885644430562117706, 0.083080502823133021,  0.0768496807577203789,
-    0.069854121318728259,  0.0620095678006706403, 0.053481524690928087,  0.0445897513247648766,
-    0.035346360791375846,  0.0254608473267153202, 0.0150079473293161225, 0.00537747987292334899};
-
-template <int PTS>
-__device__ __forceinline__ GkLane gk_lane(int r) {
-    constexpr int H = (PTS + 1) / 2;  // 8 or 16 (centre + H-1 pairs)
-    const double* X = PTS == 15 ? kX15 : kX31;
-    const double* WK = PTS == 15 ? kWk15 : kWk31;
-    const double* WG = PTS == 15 ? kWg15 : kWg31;
-    GkLane g;
-    if (r >= PTS) {  // padding lane: evaluates the centre again with zero weight
-        g.x = 0.0, g.wk = 0.0, g.wg = 0.0;
-        return g;
-    }
-    const int i = r < H ? r : r - (H - 1);  // node index 0..H-1
-    g.x = r < H ? X[i] : -X[i];
-    g.wk = WK[i];
-    // Gauss nodes of the embedded rule: the centre and the even Kronrod nodes
-    // (include/functions.h:190-199; both embedded orders, 7 and 15, are odd)
-    g.wg = (i % 2 == 0) ? WG[i / 2] : 0.0;
-    return g;
-}
-
-template <int GW>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int off = 1; off < GW; off <<= 1) v += __shfl_xor(v, off, GW);
-    return v;
-}
-
-// Adiabatic-electron closed forms kappa_e (src/Parameters.cpp:186-209).
-__device__ __forceinline__ cd kappa_e(int m, const DevParams& P, double de, double dg, cd omega) {
-    if (m == 1) {
-        // -i qR/(2 vt tau) (omega - ws_e) sgn(de)
-        const double c = P.qR / (2.0 * P.vt * P.tau) * (de / fabs(de));
-        const cd a = mk(omega.x - P.omega_s_e, omega.y);
-        return mk(c * a.y, -(c * a.x));
-    }
-    if (m == 2) {
-        const double f = (P.qR * P.qR) / (2.0 * P.vt * P.vt * P.tau) * de / fabs(de);
-        const cd wa = mk(omega.x - P.omega_s_e, omega.y);
-        const cd a = de * (omega * wa);
-        const double b1e = P.cbe * dg;
-        const cd b = (b1e * P.vt / P.qR) * mk(omega.x - P.omega_s_e * (1.0 + P.eta_e), omega.y);
-        return f * (a - b);
-    }
-    return mk(0.0, 0.0);
-}
 
 struct AsmArgs {
     DevParams P;
@@ -124,10 +37,14 @@ struct AsmArgs {
 };
 
 template <int PTS>
-__global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
+#ifndef EMME_ASM_MIN_WAVES
+#define EMME_ASM_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
-    extern __shared__ double lds_tab[];  // eta | g | b  (3N doubles)
+    constexpr int MAXD = 40;             // bisection depth the LDS interval stack can hold
+    extern __shared__ double lds_tab[];  // eta | g | b  (3N doubles) | per-group (mid, r) stack
 
     const DevParams& P = A.P;
     const int b = blockIdx.y;
@@ -139,6 +56,11 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
     const double* eta = lds_tab;
     const double* gtab = lds_tab + N;
     const double* btab = lds_tab + 2 * N;
+    // (mid, r) of every split ancestor of the current interval, one stack per lane group.
+    // All lanes of a group store the same value to the same slot and later read it back,
+    // so plain per-thread program order is enough (no cross-lane hand-off).
+    double2* stk = reinterpret_cast<double2*>(lds_tab + 3 * N + (3 * N & 1)) +
+                   (threadIdx.x / GW) * MAXD;
 
     double2* Mb = A.M + (size_t)b * dim * dim;
     const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
@@ -189,6 +111,7 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
     double dg = 0.0;
     int depth = 0;
     unsigned long long path = 0;  // index of the current interval at this depth
+    double l = qa, r = qb;        // the current interval
     double abs_tol = 0.0;
     cd sum = mk(0.0, 0.0);
     unsigned long long my_intervals = 0;
@@ -200,32 +123,16 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
         m = item - p * P.nm;
         const ushort2 ij = A.pairs[p];
         i = ij.x, j = ij.y;
-        const double bi = btab[i], bj = btab[j];
         dg = gtab[i] - gtab[j];
-        pc.de = eta[i] - eta[j];
-        pc.beta1 = P.cb * dg;
-        pc.s = sqrt(bi * bj);
-        pc.inv_s = 1.0 / pc.s;
-        pc.bsum = bi + bj;
-        const double qRd = P.qR * pc.de;
-        pc.c_lam = 0.5 * P.vt / qRd * pc.beta1;
-        pc.c_nv = qRd / P.vt;
+        pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], dg);
         depth = 0, path = 0, abs_tol = 0.0;
+        l = qa, r = qb;
         item_intervals = 0;
         sum = mk(0.0, 0.0);
     };
     if (live) load_item();
 
     while (live) {
-        // [l, r] of node (depth, path): the reference's (l+r)/2 bisection sequence
-        double l = qa, r = qb;
-        for (int s = depth - 1; s >= 0; --s) {
-            const double mid_s = (r + l) / 2;
-            if ((path >> s) & 1)
-                l = mid_s;
-            else
-                r = mid_s;
-        }
         const double mid = (r + l) / 2;
         const double scale = (r - l) / 2;
         // abscissa scale * x + mid, rounded like the reference (no FMA contraction)
@@ -238,21 +145,28 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
         ++item_intervals;
 
         // include/functions.h:203-208, 231-233
-        double err = fmax(hypot(Kx - Gx, Ky - Gy), hypot(Kx, Ky) * (2.0 * 2.220446049250313e-16));
+        const double dKx = Kx - Gx, dKy = Ky - Gy;
+        const double absK = sqrt(fma(Kx, Kx, Ky * Ky));
+        double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
         const cd integral = mk(Kx * scale, Ky * scale);
         err *= scale;
-        const double rel_abs = hypot(P.rel_tol * integral.x, P.rel_tol * integral.y);
-        if (abs_tol == 0.0) abs_tol = rel_abs;  // :237-239
-        // :240-242; ldexp(scale, max_sub) > 0.99 (b - a)
-        bool split = ldexp(scale, P.max_sub) > 0.99 * (qb - qa) &&
-                     err > abs_tol * inv_scale + P.prec_goal && err > rel_abs + P.prec_goal;
-        if (split && (depth >= 62 || item_intervals >= (1 << 18))) {  // flag and accept
+        const double rel_abs = P.rel_tol * (absK * scale);  // |rel * integral|
+        if (abs_tol == 0.0) abs_tol = rel_abs;              // :237-239
+        // :240-242.  ldexp(scale, max_sub) > 0.99 (b - a) with scale = (b-a) 2^-(depth+1)
+        // (up to rounding far below the 1 % margin) is exactly depth < max_sub.
+        bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
+                     err > rel_abs + P.prec_goal;
+        if (split && (depth >= MAXD || item_intervals >= (1 << 18))) {  // flag and accept
             split = false;
             bad = 1;
         }
         if (split) {
+            // left half first (the reference pushes [mid,r] then [l,mid]); remember the
+            // right half's bounds for when the walk comes back up
+            stk[depth] = make_double2(mid, r);
+            r = mid;
             ++depth;
-            path <<= 1;  // left half first (the reference pushes [mid,r] then [l,mid])
+            path <<= 1;
         } else {
             sum = sum + integral;
             ++path;
@@ -268,14 +182,7 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
                 if (lane_in_group == 0) {
                     if (m == 0) {
                         // A_ij = -kappa_all(0) W_ij dx (include/solver.h:448-453)
-                        double w = (j - i) <= 5
-                                       ? (j - i == 1   ? 2.951388888888883
-                                          : j - i == 2 ? -2.4305555555555305
-                                          : j - i == 3 ? 4.166666666667441
-                                          : j - i == 4 ? -0.3472222222224549
-                                                       : 1.159722222222284)
-                                       : 1.0;
-                        if (j == N - 1) w -= 0.5;  // src/singularity_handler.cpp:18 (j>i>=0)
+                        const double w = pair_weight(i, j, N);
                         const cd v = (-(w * P.dx)) * kap;
                         store(i, j, v);
                         store(j, i, v);
@@ -295,6 +202,11 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs A) {
                 item += ngroups;
                 live = item < nitems;
                 if (live) load_item();
+            } else {
+                // right sibling of the ancestor that was split at depth-1
+                const double2 pr = stk[depth - 1];
+                l = pr.x;
+                r = pr.y;
             }
         }
     }
@@ -331,7 +243,8 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream) {
     if (gx < 1) gx = 1;
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)L.nbatch), block(256);
-    const size_t lds = (size_t)3 * L.P.N * sizeof(double);
+    const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
+                       (size_t)groups_per_block * 40 * sizeof(double2);
     if (L.gk_points == 15)
         hipLaunchKernelGGL(k_assemble<15>, grid, block, lds, stream, A);
     else

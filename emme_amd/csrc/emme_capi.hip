@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -62,6 +63,9 @@ struct emme_ctx {
     double *d_omega = nullptr, *d_domega = nullptr, *d_tr = nullptr;
     int *d_active = nullptr, *d_iters = nullptr, *d_info = nullptr, *d_status = nullptr;
     unsigned long long* d_intervals = nullptr;
+    int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
+    std::vector<int> h_actidx; // its host image (kept alive across the async upload)
+    int wl_min = 4;            // use the omega-lane kernel from this many active items on
     int mat_cap = 0;  // matrices per set
     double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
     double* d_iterates = nullptr;
@@ -137,7 +141,7 @@ int ensure_batch(emme_ctx* c, int nb) {
         p = nullptr;
     };
     F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active), F(c->d_iters), F(c->d_info),
-        F(c->d_status), F(c->d_intervals);
+        F(c->d_status), F(c->d_intervals), F(c->d_actidx);
     c->cap = 0;
     HIP_TRY(hipMalloc((void**)&c->d_omega, sizeof(double) * 2 * nb));
     HIP_TRY(hipMalloc((void**)&c->d_domega, sizeof(double) * 2 * nb));
@@ -147,6 +151,7 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(hipMalloc((void**)&c->d_info, sizeof(int) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(int) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_actidx, sizeof(int) * nb));
     c->cap = nb;
     return EMME_OK;
 }
@@ -169,11 +174,11 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
     return EMME_OK;
 }
 
-int items_per_group_for(const emme_ctx* c, int nbatch) {
+int items_per_group_for(const emme_ctx* c, long units) {
     // enough lane groups to give every SIMD several waves, but a few integrals per group
     // when the batch is large so the start-up cost (table staging) is amortised
     const int gw = c->p.integration_start_points == 15 ? 16 : 32;
-    const long total = (long)c->npairs * c->nm * nbatch;
+    const long total = (long)c->npairs * c->nm * units;
     const long target_groups = 256L * 16 * (64 / gw) * 4;
     long ipg = total / target_groups;
     if (ipg < 1) ipg = 1;
@@ -181,14 +186,17 @@ int items_per_group_for(const emme_ctx* c, int nbatch) {
     return (int)ipg;
 }
 
-int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active, double* d_M,
-                const double* d_Mold, double* d_Mp, const double* d_domega) {
+// host_active: which of the nbatch items to assemble (null = all).  Batches of wl_min or
+// more items go through the omega-lane kernel, which shares the omega-independent node
+// data between items; smaller ones through the lanes-are-nodes kernel.
+int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
+                const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
+                const double* d_domega) {
     AssembleLaunch L;
     L.P = c->P;
     L.gk_points = c->p.integration_start_points;
     L.nbatch = nbatch;
     L.npairs = c->npairs;
-    L.items_per_group = items_per_group_for(c, nbatch);
     L.tab = c->d_tab;
     L.pairs = c->d_pairs;
     L.omega = d_omega;
@@ -199,11 +207,25 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     L.domega = d_domega;
     L.intervals = c->d_intervals;
     L.status = c->d_status;
-    {
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));  // previous upload of h_actidx done
+    std::vector<int>& idx = c->h_actidx;
+    idx.clear();
+    for (int b = 0; b < nbatch; ++b)
+        if (!host_active || host_active[b] != 0) idx.push_back(b);
+    const int n_act = (int)idx.size();
+    if (n_act == 0) return EMME_OK;
+    if (n_act >= c->wl_min) {
+        const int gw = L.gk_points == 15 ? 16 : 32;
+        L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
+        HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
+        ScopedSpan s(c, K_ASM);
+        HIP_TRY(launch_assemble_wl(L, c->d_actidx, n_act, c->stream));
+    } else {
+        L.items_per_group = items_per_group_for(c, nbatch);
         ScopedSpan s(c, K_ASM);
         HIP_TRY(launch_assemble(L, c->stream));
     }
-    c->acc.matrices += nbatch;  // upper bound when some items are inactive
+    c->acc.matrices += n_act;
     return EMME_OK;
 }
 
@@ -244,6 +266,7 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     emme_ctx* c = new emme_ctx;
     c->p = *p;
     c->device = device;
+    if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
     const int N = p->npoints;
     c->N = N;
     const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
@@ -353,7 +376,7 @@ int emme_assemble_batch(emme_ctx_t* c, const double* omega, int nbatch, double* 
     HIP_TRY(hipMemcpyAsync(c->d_omega, omega, sizeof(double) * 2 * nbatch, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_intervals, 0, sizeof(unsigned long long) * nbatch, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * nbatch, c->stream));
-    rc = do_assemble(c, nbatch, c->d_omega, nullptr, dM, nullptr, nullptr, nullptr);
+    rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, dM, nullptr, nullptr, nullptr);
     if (rc) return rc;
     if (!dev_out)
         HIP_TRY(hipMemcpyAsync(M, dM, mat_doubles(c) * sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
@@ -461,7 +484,7 @@ int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nba
         HIP_TRY(launch_newton_update(nbatch, c->d_tr, c->d_omega, c->d_domega, nullptr, nullptr,
                                      c->d_info, 0.0, nullptr, 0, 0, c->stream));
     }
-    rc = do_assemble(c, nbatch, c->d_omega, nullptr, dM, c->d_Mold, dMp, c->d_domega);
+    rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, dM, c->d_Mold, dMp, c->d_domega);
     if (rc) return rc;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(M, dM, mbytes, hipMemcpyDeviceToHost, c->stream));
@@ -523,14 +546,14 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * n, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_omega, w0.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_domega, dw.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-    rc = do_assemble(c, n, c->d_omega, nullptr, c->d_Mold, nullptr, nullptr, nullptr);
+    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_Mold, nullptr, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // w0 is reused as the staging buffer below
     HIP_TRY(hipMemcpyAsync(c->d_omega, w1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-    rc = do_assemble(c, n, c->d_omega, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
+    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
     if (rc) return rc;
 
-    std::vector<int> act(n);
+    std::vector<int> act(n, 1);
     for (int j = 0; j <= step_limit; ++j) {  // src/main.cpp:43
         {
             ScopedSpan s(c, K_OTHER);
@@ -546,7 +569,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             HIP_TRY(launch_newton_update(n, c->d_tr, c->d_omega, c->d_domega, c->d_active, c->d_iters,
                                          c->d_info, tol, c->d_iterates, j, stride, c->stream));
         }
-        rc = do_assemble(c, n, c->d_omega, c->d_active, c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
+        rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
         if (rc) return rc;
         {
             ScopedSpan s(c, K_OTHER);

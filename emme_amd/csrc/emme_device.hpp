@@ -35,12 +35,85 @@ __device__ __forceinline__ cd operator*(double s, cd a) { return cd{s * a.x, s *
 __device__ __forceinline__ cd operator*(cd a, double s) { return cd{s * a.x, s * a.y}; }
 __device__ __forceinline__ double norm2(cd a) { return fma(a.x, a.x, a.y * a.y); }
 __device__ __forceinline__ cd conj(cd a) { return cd{a.x, -a.y}; }
-__device__ __forceinline__ cd rcp(cd a) {
-    const double d = 1.0 / norm2(a);
-    return cd{a.x * d, -(a.y * d)};
-}
 // multiply by i
 __device__ __forceinline__ cd times_i(cd a) { return cd{-a.y, a.x}; }
+
+// 1/x and 1/sqrt(x) for normal-range arguments: hardware seed (v_rcp_f64 / v_rsq_f64) +
+// two Newton steps, i.e. the compiler's own division sequence without the range scaling
+// and fix-up instructions that exist for subnormal/overflow operands (never met here).
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double frsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
+    y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
+    return y;
+}
+
+__device__ __forceinline__ cd rcp(cd a) {
+    const double d = frcp(norm2(a));
+    return cd{a.x * d, -(a.y * d)};
+}
+
+// sin and cos of a moderate argument (|x| < ~1e9): three-term Cody-Waite reduction by pi/2
+// carried by FMAs (the first FMA x - n*C1 is exact by cancellation), then the classical
+// degree-13 / degree-14 minimax kernels on [-pi/4, pi/4].  ~1 ulp, no slow path: the
+// phase of the integrand's exponent stays far below 1e9 wherever the clamp lets it live.
+__device__ __forceinline__ void fsincos(double x, double& s, double& c) {
+    const double n = rint(x * 0.63661977236758134308);  // 2/pi
+    double r = fma(-n, 1.5707963267948965580e+00, x);
+    r = fma(-n, 6.1232339957367660359e-17, r);
+    r = fma(-n, -1.4973849048591698329e-33, r);
+    const double z = r * r;
+    // sin kernel
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(r * z, ps, r);
+    // cos kernel
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double wv = 1.0 - hz;
+    const double cs = wv + (((1.0 - wv) - hz) + z * (z * pc));
+    const int q = (int)n & 3;
+    const double s0 = (q & 1) ? cs : sn;
+    const double c0 = (q & 1) ? sn : cs;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// exp(x) for x in the clamp's range [-40, 709]: x = k ln2 + r, degree-13 Taylor polynomial
+// on |r| <= ln2/2 (truncation 4e-18) evaluated by Horner, scaled with ldexp.
+__device__ __forceinline__ double fexp(double x) {
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;           // 1/13!
+    p = fma(p, r, 2.0876756987868100e-09);       // 1/12!
+    p = fma(p, r, 2.5052108385441720e-08);       // 1/11!
+    p = fma(p, r, 2.7557319223985888e-07);       // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);       // 1/9!
+    p = fma(p, r, 2.4801587301587302e-05);       // 1/8!
+    p = fma(p, r, 1.9841269841269841e-04);       // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);       // 1/6!
+    p = fma(p, r, 8.3333333333333332e-03);       // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);       // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);       // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
 
 // Scalars shared by every work item of a launch (passed by value as a kernel argument).
 struct DevParams {
@@ -81,31 +154,61 @@ struct OmegaConst {
 // Miller backward recurrence for the unnormalised I0, I1 of complex z = s / lambda
 // (include/functions.h:381-408).  `w` = lambda / s, so the reference's `2n / z * p`
 // becomes (2n) * (w * p) with no division.  Returns y0, y1 and mu + y0.
-__device__ __forceinline__ void bessel_miller(cd w, double zabs, bool re_z_neg, cd& y0, cd& y1,
-                                              cd& mutot) {
-    int n = (int)floor(zabs) + 1;
-    cd p0 = mk(0.0, 0.0), p1 = mk(1.0, 0.0);
-    // threshold evaluated once with p1 = 1: |p0 - 2n/z p1| = 2n/|z|  (functions.h:388-390)
-    double test = fmax(sqrt(2.e+7 * (2.0 * n / zabs)), 2.e+7);
-    const double test2 = test * test;
-    int guard = 0;
-    while (norm2(p1) <= test2 && guard < 4096) {  // guard: every wave must terminate
-        const cd t = p0 - (2.0 * n) * (w * p1);
-        p0 = p1;
-        p1 = t;
-        ++n;
-        ++guard;
+__device__ __forceinline__ void bessel_miller(cd w, double zabs, double inv_zabs, bool re_z_neg,
+                                              cd& y0, cd& y1, cd& mutot) {
+    const int n0 = (int)floor(zabs) + 1;
+    double tn = 2.0 * n0;  // 2n, carried as a double (no per-step int->double conversion)
+    // threshold evaluated once with p1 = 1: |p0 - 2n/z p1| = 2n/|z|  (functions.h:388-390);
+    // compared on squares: test^2 = max(2e7 * 2n/|z|, 4e14)
+    const double test2 = fmax(2.e+7 * (tn * inv_zabs), 4.e+14);
+    // Upward recurrence p_{k+1} = p_{k-1} - (2n/z) p_k until |p| exceeds the threshold.
+    // Two steps per trip with the roles of (a, b) swapped, so no register rotation.
+    cd a = mk(0.0, 0.0), b = mk(1.0, 0.0);  // (previous, latest)
+    int steps = 0;
+    for (;;) {
+        if (!(norm2(b) <= test2) || steps >= 4096) break;  // cap: every wave must terminate
+        cd q = w * b;
+        a = mk(fma(-tn, q.x, a.x), fma(-tn, q.y, a.y));  // a is now the latest
+        tn += 2.0;
+        ++steps;
+        if (!(norm2(a) <= test2) || steps >= 4096) {
+            b = a;
+            break;
+        }
+        q = w * a;
+        b = mk(fma(-tn, q.x, b.x), fma(-tn, q.y, b.y));
+        tn += 2.0;
+        ++steps;
     }
-    y0 = rcp(p1);
-    y1 = mk(0.0, 0.0);
+    // Downward recurrence from n-1 to 1 (functions.h:397-405):
+    //   y_new = (2n/z) y0 + y1;  mu += 2 (Re z < 0 ? 1 - 2 (n & 1) : 1) * (old y0)
+    int n = n0 + steps - 1;  // first n of the loop
+    tn -= 2.0;
+    cd u = rcp(b), v = mk(0.0, 0.0);  // (latest y0, previous y1)
     cd mu = mk(0.0, 0.0);
-    for (n--; n > 0; --n) {
-        const cd t = (2.0 * n) * (w * y0) + y1;
-        y1 = y0;
-        y0 = t;
-        const double sg = re_z_neg ? (double)(2 - 4 * (n & 1)) : 2.0;  // 2*(1-2(n&1)) or 2
-        mu = mu + sg * y1;
+    double sg = re_z_neg ? ((n & 1) ? -2.0 : 2.0) : 2.0;
+    const double flip = re_z_neg ? -1.0 : 1.0;
+    for (; n >= 2; n -= 2) {
+        cd q = w * u;
+        v = mk(fma(tn, q.x, v.x), fma(tn, q.y, v.y));  // v is now the latest
+        mu = mk(fma(sg, u.x, mu.x), fma(sg, u.y, mu.y));
+        sg *= flip;
+        tn -= 2.0;
+        q = w * v;
+        u = mk(fma(tn, q.x, u.x), fma(tn, q.y, u.y));  // u is the latest again
+        mu = mk(fma(sg, v.x, mu.x), fma(sg, v.y, mu.y));
+        sg *= flip;
+        tn -= 2.0;
     }
+    if (n == 1) {
+        const cd q = w * u;
+        const cd t = mk(fma(tn, q.x, v.x), fma(tn, q.y, v.y));
+        mu = mk(fma(sg, u.x, mu.x), fma(sg, u.y, mu.y));
+        v = u;
+        u = t;
+    }
+    y0 = u;
+    y1 = v;
     mutot = mu + y0;
 }
 
@@ -120,64 +223,172 @@ __device__ __forceinline__ void bessel_miller(cd w, double zabs, bool re_z_neg, 
 // and the underflow clamp of :167-173 tested before the Bessel recurrence (its argument
 // needs only z = s/lambda), which skips the recurrence and the complex exp where the
 // integrand is exactly zero.
+// Everything the integrand derives from (t, 1/t, u) and the pair constants.
+struct NodeTerms {
+    cd e, taut, lam, rl, nv, nv2;
+    double r2, ou, rlabs;
+};
+__device__ __forceinline__ NodeTerms node_terms(double t, double inv_t, double u,
+                                                const PairConst& pc, double omi) {
+    NodeTerms n;
+    const double r1 = frsqrt(fma(u, u, 1.0));
+    n.r2 = r1 * r1;
+    n.ou = omi * u;
+    n.e = mk(r1, -(n.ou * r1));
+    n.taut = t * n.e;
+    n.lam = mk(fma(-pc.c_lam, n.taut.y, 1.0), pc.c_lam * n.taut.x);
+    n.rlabs = frsqrt(norm2(n.lam));  // 1 / |lambda|
+    const double rl2 = n.rlabs * n.rlabs;
+    n.rl = mk(n.lam.x * rl2, -(n.lam.y * rl2));  // 1 / lambda
+    n.nv = (pc.c_nv * inv_t) * conj(n.e);
+    n.nv2 = n.nv * n.nv;
+    return n;
+}
+
+#ifndef EMME_REMAT
+#define EMME_REMAT 0
+#endif
+#ifndef EMME_FAST_TRANSCENDENTALS
+#define EMME_FAST_TRANSCENDENTALS 1
+#endif
+
 __device__ __forceinline__ cd integrand(double x, const DevParams& P, const PairConst& pc,
                                         const OmegaConst& oc, int m) {
     double sx, cx;
     sincos(x, &sx, &cx);
-    const double inv_cx = 1.0 / cx;
-    const double t = sx * inv_cx;
+    const double rsc = frcp(sx * cx);
+    const double inv_cx = sx * rsc;
+    double t = sx * inv_cx;
     const double inv_c2 = inv_cx * inv_cx;
-    const double inv_t = cx / sx;
+    double inv_t = cx * (cx * rsc);
+    double u = t * P.inv_arc;
 
-    const double u = t * P.inv_arc;
-    const double r2 = 1.0 / fma(u, u, 1.0);
-    const double r1 = sqrt(r2);
-    const double ou = oc.omi * u;
-    const cd e = mk(r1, -(ou * r1));
-    const cd taut = t * e;
-    const cd jt = mk(inv_t, -(ou * r2 * inv_t));  // jacob / t~
-
-    const cd lam = mk(fma(-pc.c_lam, taut.y, 1.0), pc.c_lam * taut.x);
-    const double rl2 = 1.0 / norm2(lam);
-    const cd rl = mk(lam.x * rl2, -(lam.y * rl2));  // 1 / lambda
-    const cd z = pc.s * rl;
-
-    const cd nv = (pc.c_nv * inv_t) * conj(e);
-    const cd nv2 = nv * nv;
-
-    // log_coef, src/Parameters.cpp:154-165
-    cd L = (-0.5) * nv2 + times_i(taut * oc.omega);
-    L = L + (-0.5 * pc.beta1) * times_i(nv);
-    L = L - (0.5 * pc.bsum) * rl;
-    const bool zneg = z.x < 0.0;
-    const cd arg = zneg ? (L - z) : (L + z);  // log_coef - (Re z<0 ? z : -z)
-    if (!(arg.x >= -40.)) {
-        // safe_exp clamp (:167-173); NaN also lands here and is propagated below
-        if (arg.x < -40.) return mk(0.0, 0.0);
+    // ---- stage A: exponent of the integrand and the underflow clamp -----------------
+    cd arg, w;
+    double zabs, inv_zabs;
+    bool zneg;
+    {
+        const NodeTerms n = node_terms(t, inv_t, u, pc, oc.omi);
+        const cd z = pc.s * n.rl;
+        // log_coef, src/Parameters.cpp:154-165
+        cd L = (-0.5) * n.nv2 + times_i(n.taut * oc.omega);
+        L = L + (-0.5 * pc.beta1) * times_i(n.nv);
+        L = L - (0.5 * pc.bsum) * n.rl;
+        zneg = z.x < 0.0;
+        arg = zneg ? (L - z) : (L + z);  // log_coef - (Re z<0 ? z : -z)
+        if (!(arg.x >= -40.)) {
+            // safe_exp clamp (:167-173); NaN falls through and is propagated below
+            if (arg.x < -40.) return mk(0.0, 0.0);
+        }
+        w = pc.inv_s * n.lam;
+        zabs = pc.s * n.rlabs;
+        inv_zabs = pc.inv_s * (norm2(n.lam) * n.rlabs);
     }
+
+    // ---- stage B: Miller recurrence (the long, data-dependent part) -------------------
+    cd y0, y1, mutot;
+    bessel_miller(w, zabs, inv_zabs, zneg, y0, y1, mutot);
+
+#if EMME_REMAT
+    // Only (t, 1/t, u, 1/cos^2, arg) are meant to stay live across the recurrence; the
+    // node terms are recomputed (~45 instructions) instead of being held in ~30 VGPRs.
+    asm volatile("" : "+v"(t), "+v"(inv_t), "+v"(u));
+#endif
+    // ---- stage C: coefficients and assembly of F ---------------------------------------
+    const NodeTerms n = node_terms(t, inv_t, u, pc, oc.omi);
     double sa, ca;
+#if EMME_FAST_TRANSCENDENTALS
+    fsincos(arg.y, sa, ca);
+    const double ea = fexp(arg.x);
+#else
     sincos(arg.y, &sa, &ca);
     const double ea = exp(arg.x);
+#endif
     const cd sexp = mk(ea * ca, ea * sa);
 
-    cd y0, y1, mutot;
-    bessel_miller(pc.inv_s * lam, pc.s * sqrt(rl2), zneg, y0, y1, mutot);
-
-    const cd rl3 = rl * rl * rl;  // lambda^-3 (reference: pow(lambda, -3.) via log/polar)
+    const cd rl3 = n.rl * n.rl * n.rl;  // lambda^-3 (reference: pow(lambda, -3.) via log/polar)
     const double wsi_eta = P.omega_s_i * P.eta_i;
-    cd a0 = oc.omega - P.omega_s_i * mk(fma(P.eta_i, fma(0.5, nv2.x, -1.5), 1.0),
-                                         P.eta_i * 0.5 * nv2.y);
-    cd i0c = a0 * rl + (wsi_eta * mk(0.5 * pc.bsum - lam.x, -lam.y)) * rl3;
-    cd i1c = (-wsi_eta * pc.s) * rl3;
+    const cd a0 = oc.omega - P.omega_s_i * mk(fma(P.eta_i, fma(0.5, n.nv2.x, -1.5), 1.0),
+                                               P.eta_i * 0.5 * n.nv2.y);
+    const cd i0c = a0 * n.rl + (wsi_eta * mk(0.5 * pc.bsum - n.lam.x, -n.lam.y)) * rl3;
+    const cd i1c = (-wsi_eta * pc.s) * rl3;
 
-    cd F = jt * sexp;
+    cd F = mk(inv_t, -(n.ou * n.r2 * inv_t)) * sexp;  // (jacob / t~) * safe_exp
     if (m == 1)
-        F = F * nv;
+        F = F * n.nv;
     else if (m == 2)
-        F = F * nv2;
+        F = F * n.nv2;
     F = F * (i0c * y0 + i1c * y1);
     F = F * rcp(mutot);
     return inv_c2 * F;
+}
+
+// ---- omega-independent half of the integrand ------------------------------------------
+// For fixed pair, moment and contour sense (omi) the integrand at abscissa x is
+//     F(omega) = exp(A0 + T omega) (omega Q1 + Q0)      [0 when Re(A0 + T omega) < -40]
+// with  T  = i t~,
+//       A0 = -nv^2/2 - i beta_1 nv/2 - bsum/(2 lambda) -/+ z          (log_coef without i t~ omega)
+//       Q1 = pre * y0/lambda,   Q0 = pre * (C0 y0 + i1c y1),
+//       pre = nv^m (jacob/t~) / (mu cos^2 x),
+//       C0 = -ws_i (1 + eta_i (nv^2/2 - 3/2))/lambda + ws_i eta_i (bsum/2 - lambda)/lambda^3.
+// Everything expensive -- sincos(x), the two rsqrt, the Miller recurrence -- lives here and
+// is shared by every omega of a batch (src/Parameters.cpp:120-176 regrouped by omega).
+struct NodeData {
+    cd A0, T, Q1, Q0;
+};
+__device__ __forceinline__ NodeData node_data(double x, const DevParams& P, const PairConst& pc,
+                                              double omi, int m) {
+    double sx, cx;
+    sincos(x, &sx, &cx);
+    const double rsc = frcp(sx * cx);
+    const double inv_cx = sx * rsc;
+    const double t = sx * inv_cx;
+    const double inv_c2 = inv_cx * inv_cx;
+    const double inv_t = cx * (cx * rsc);
+    const double u = t * P.inv_arc;
+    const NodeTerms n = node_terms(t, inv_t, u, pc, omi);
+
+    const cd z = pc.s * n.rl;
+    const bool zneg = z.x < 0.0;
+    cd L0 = (-0.5) * n.nv2 + (-0.5 * pc.beta1) * times_i(n.nv);
+    L0 = L0 - (0.5 * pc.bsum) * n.rl;
+
+    cd y0, y1, mutot;
+    bessel_miller(pc.inv_s * n.lam, pc.s * n.rlabs, pc.inv_s * (norm2(n.lam) * n.rlabs), zneg, y0,
+                  y1, mutot);
+
+    const cd rl3 = n.rl * n.rl * n.rl;
+    const double wsi_eta = P.omega_s_i * P.eta_i;
+    const cd c0 = (-P.omega_s_i) * (mk(fma(P.eta_i, fma(0.5, n.nv2.x, -1.5), 1.0),
+                                       P.eta_i * 0.5 * n.nv2.y) * n.rl) +
+                  (wsi_eta * mk(0.5 * pc.bsum - n.lam.x, -n.lam.y)) * rl3;
+    const cd i1c = (-wsi_eta * pc.s) * rl3;
+
+    cd pre = mk(inv_t, -(n.ou * n.r2 * inv_t));  // jacob / t~
+    if (m == 1)
+        pre = pre * n.nv;
+    else if (m == 2)
+        pre = pre * n.nv2;
+    pre = (inv_c2 * pre) * rcp(mutot);
+
+    NodeData d;
+    d.A0 = zneg ? (L0 - z) : (L0 + z);
+    d.T = times_i(n.taut);
+    d.Q1 = pre * (n.rl * y0);
+    d.Q0 = pre * (c0 * y0 + i1c * y1);
+    return d;
+}
+
+// omega-dependent half: one complex exponential and three complex products.
+__device__ __forceinline__ cd node_eval(const NodeData& d, cd omega) {
+    const cd arg = d.A0 + d.T * omega;
+    if (!(arg.x >= -40.)) {
+        if (arg.x < -40.) return mk(0.0, 0.0);  // safe_exp clamp, src/Parameters.cpp:167-173
+    }
+    double sa, ca;
+    fsincos(arg.y, sa, ca);
+    const double ea = fexp(arg.x);
+    return mk(ea * ca, ea * sa) * (omega * d.Q1 + d.Q0);
 }
 
 // Gauss-Kronrod node tables laid out per lane of a group (centre, +x_1..+x_h, -x_1..-x_h,

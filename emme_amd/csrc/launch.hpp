@@ -24,6 +24,10 @@ struct AssembleLaunch {
     int* status;         // device
 };
 hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream);
+// omega-lane form (assemble_wl.hip): the n_act batch items listed in act_idx (device) share
+// the omega-independent node data; L.active is ignored.
+hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n_act,
+                              hipStream_t stream);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
