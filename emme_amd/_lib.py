@@ -63,7 +63,7 @@ class Profile(C.Structure):
         ("linstep_ms", C.c_double), ("linstep_launches", C.c_long),
         ("other_ms", C.c_double), ("other_launches", C.c_long),
         ("gk_intervals", C.c_longlong), ("integrand_evals", C.c_longlong),
-        ("matrices", C.c_longlong),
+        ("matrices", C.c_longlong), ("union_rounds", C.c_longlong),
     ]
 
 

@@ -41,6 +41,7 @@ struct AsmWlArgs {
     const double2* domega;
     unsigned long long* intervals;  // [nbatch]
     int* status;                    // [nbatch]
+    unsigned long long* rounds;     // [1] interval rounds walked by all groups (diagnostic)
 };
 
 #ifndef EMME_WL_MIN_WAVES
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
     unsigned long long my_intervals = 0;
     int item_intervals = 0;
     int bad = 0;
+    unsigned long long my_rounds = 0;
 
     auto load_item = [&]() {
         const int p = item / P.nm;
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
         const double mid = (r + l) / 2;
         const double scale = (r - l) / 2;
         const bool need = !my_done && my_depth == depth && my_path == path;
+        ++my_rounds;
         bool my_split = false;
 
 #pragma unroll 1
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
         }
     }
 
+    if (A.rounds && lane == 0 && my_rounds) atomicAdd(A.rounds, my_rounds);
     if (has_w) {
         if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
         if (bad) A.status[b] = 1;
@@ -309,6 +313,7 @@ hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n
     A.domega = (const double2*)L.domega;
     A.intervals = L.intervals;
     A.status = L.status;
+    A.rounds = L.rounds;
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     const int chunks = (n_act + gw - 1) / gw;

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -63,6 +64,7 @@ struct emme_ctx {
     double *d_omega = nullptr, *d_domega = nullptr, *d_tr = nullptr;
     int *d_active = nullptr, *d_iters = nullptr, *d_info = nullptr, *d_status = nullptr;
     unsigned long long* d_intervals = nullptr;
+    unsigned long long* d_rounds = nullptr;  // diagnostic counter of the omega-lane kernel
     int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
@@ -152,6 +154,10 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(int) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_actidx, sizeof(int) * nb));
+    if (!c->d_rounds) {
+        HIP_TRY(hipMalloc((void**)&c->d_rounds, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_rounds, 0, sizeof(unsigned long long)));
+    }
     c->cap = nb;
     return EMME_OK;
 }
@@ -174,6 +180,15 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
     return EMME_OK;
 }
 
+// the Newton linear step: blocked kernel while its panel fits in LDS, else the unblocked one
+hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, const int* active,
+                       double* tr, int* info) {
+    static const bool force_unblocked = std::getenv("EMME_LU_UNBLOCKED") != nullptr;
+    if (!force_unblocked && trace_solve_blocked_lds(n) <= 150 * 1024)
+        return launch_trace_solve_blocked(n, nbatch, A, B, active, tr, info, c->stream);
+    return launch_trace_solve(n, nbatch, A, B, active, tr, info, c->stream);
+}
+
 int items_per_group_for(const emme_ctx* c, long units) {
     // enough lane groups to give every SIMD several waves, but a few integrals per group
     // when the batch is large so the start-up cost (table staging) is amortised
@@ -191,7 +206,7 @@ int items_per_group_for(const emme_ctx* c, long units) {
 // data between items; smaller ones through the lanes-are-nodes kernel.
 int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
                 const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
-                const double* d_domega) {
+                const double* d_domega, const unsigned long long* cost = nullptr) {
     AssembleLaunch L;
     L.P = c->P;
     L.gk_points = c->p.integration_start_points;
@@ -207,6 +222,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     L.domega = d_domega;
     L.intervals = c->d_intervals;
     L.status = c->d_status;
+    L.rounds = c->d_rounds;
     if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));  // previous upload of h_actidx done
     std::vector<int>& idx = c->h_actidx;
     idx.clear();
@@ -214,6 +230,11 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (!host_active || host_active[b] != 0) idx.push_back(b);
     const int n_act = (int)idx.size();
     if (n_act == 0) return EMME_OK;
+    // Items that share a lane group walk the union of their quadrature trees, so a cheap
+    // item next to an expensive one costs as much as the expensive one: group items of
+    // similar cost (interval count of their previous assembly) together.
+    if (cost)
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     if (n_act >= c->wl_min) {
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
@@ -329,7 +350,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     };
     F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
         F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_M), F(c->d_Mold),
-        F(c->d_Mp), F(c->d_work), F(c->d_iterates);
+        F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     delete c;
@@ -355,6 +376,12 @@ int emme_ctx_profile_read(emme_ctx_t* c, emme_profile_t* out, int reset) {
     int rc = drain_spans(c);
     if (rc) return rc;
     c->acc.integrand_evals = c->acc.gk_intervals * c->p.integration_start_points;
+    if (c->d_rounds) {
+        unsigned long long r = 0;
+        HIP_TRY(hipMemcpy(&r, c->d_rounds, sizeof r, hipMemcpyDeviceToHost));
+        c->acc.union_rounds = (long long)r;
+        if (reset) HIP_TRY(hipMemset(c->d_rounds, 0, sizeof r));
+    }
     *out = c->acc;
     if (reset) c->acc = emme_profile_t{};
     return EMME_OK;
@@ -427,7 +454,7 @@ int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* 
     }
     {
         ScopedSpan s(c, K_LIN);
-        HIP_TRY(launch_trace_solve(n, nbatch, dA, dB, nullptr, c->d_tr, c->d_info, c->stream));
+        HIP_TRY(trace_solve(c, n, nbatch, dA, dB, nullptr, c->d_tr, c->d_info));
     }
     HIP_TRY(hipMemcpyAsync(tr, c->d_tr, sizeof(double) * 2 * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
@@ -477,7 +504,7 @@ int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nba
     }
     {
         ScopedSpan s(c, K_LIN);
-        HIP_TRY(launch_trace_solve(c->dim, nbatch, c->d_work, dMp, nullptr, c->d_tr, c->d_info, c->stream));
+        HIP_TRY(trace_solve(c, c->dim, nbatch, c->d_work, dMp, nullptr, c->d_tr, c->d_info));
     }
     {
         ScopedSpan s(c, K_OTHER);
@@ -546,14 +573,28 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * n, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_omega, w0.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_domega, dw.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    std::vector<int> act(n, 1);
+    std::vector<unsigned long long> iv_prev(n, 0), iv_now(n, 0), cost(n, 0), iv_prev_dbg(n, 0);
+    auto refresh_cost = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(iv_now.data(), c->d_intervals, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int b = 0; b < n; ++b) {
+            if (iv_now[b] != iv_prev[b]) cost[b] = iv_now[b] - iv_prev[b];
+            iv_prev[b] = iv_now[b];
+        }
+        return EMME_OK;
+    };
     rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_Mold, nullptr, nullptr, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // w0 is reused as the staging buffer below
+    rc = refresh_cost();  // synchronises; the first fill's interval counts order the second
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_omega, w1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
+    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
+                     cost.data());
     if (rc) return rc;
 
-    std::vector<int> act(n, 1);
+    rc = refresh_cost();
+    if (rc) return rc;
     for (int j = 0; j <= step_limit; ++j) {  // src/main.cpp:43
         {
             ScopedSpan s(c, K_OTHER);
@@ -562,21 +603,40 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         }
         {
             ScopedSpan s(c, K_LIN);
-            HIP_TRY(launch_trace_solve(c->dim, n, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info, c->stream));
+            HIP_TRY(trace_solve(c, c->dim, n, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info));
         }
         {
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(launch_newton_update(n, c->d_tr, c->d_omega, c->d_domega, c->d_active, c->d_iters,
                                          c->d_info, tol, c->d_iterates, j, stride, c->stream));
         }
-        rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega);
+        rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
+                         cost.data());
         if (rc) return rc;
         {
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(launch_retire(n, c->d_active, c->stream));
         }
         HIP_TRY(hipMemcpyAsync(act.data(), c->d_active, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = refresh_cost();  // also synchronises the stream
+        if (rc) return rc;
+        if (std::getenv("EMME_DEBUG")) {
+            static unsigned long long last_rounds = 0;
+            unsigned long long r = 0, tot = 0, mx = 0;
+            (void)hipMemcpy(&r, c->d_rounds, sizeof r, hipMemcpyDeviceToHost);
+            int na = 0, nprev = 0;
+            for (int b = 0; b < n; ++b) {
+                if (iv_now[b] != iv_prev_dbg[b]) {
+                    const unsigned long long d = iv_now[b] - iv_prev_dbg[b];
+                    tot += d, mx = d > mx ? d : mx, ++nprev;
+                }
+                iv_prev_dbg[b] = iv_now[b];
+                na += act[b] != 0;
+            }
+            fprintf(stderr, "[emme] iter %2d: assembled %3d, lane-intervals %10llu (max/item %9llu), rounds %9llu, fill %.3f, still active %d\n",
+                    j, nprev, tot, mx, r - last_rounds, tot / (16.0 * (double)(r - last_rounds + 1)), na);
+            last_rounds = r;
+        }
         bool any = false;
         for (int b = 0; b < n; ++b) any |= act[b] != 0;
         if (!any) break;

@@ -22,6 +22,7 @@ struct AssembleLaunch {
     const double* domega; // device (needed when Mold != null)
     unsigned long long* intervals;  // device or null
     int* status;         // device
+    unsigned long long* rounds = nullptr;  // device [1], omega-lane kernel diagnostic
 };
 hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream);
 // omega-lane form (assemble_wl.hip): the n_act batch items listed in act_idx (device) share
@@ -32,6 +33,11 @@ hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
                               double* tr /*2*nbatch*/, int* info, hipStream_t stream);
+
+// Blocked version (linstep_blocked.hip); usable while its LDS panel fits (n <= ~560).
+size_t trace_solve_blocked_lds(int n);
+hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
+                                      double* tr, int* info, hipStream_t stream);
 
 // domega = -1/tr; omega += domega; iters += 1; active = !(|domega| < tol |omega|) && info == 0
 // (include/solver.h:139-140, src/main.cpp:53-56). `iterates` (nullable) records omega.

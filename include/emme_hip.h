@@ -55,6 +55,7 @@ typedef struct emme_profile {
     long long gk_intervals;   /* Gauss-Kronrod intervals evaluated (all launches)    */
     long long integrand_evals; /* = intervals * integration_start_points             */
     long long matrices;       /* matrices assembled                                  */
+    long long union_rounds;   /* omega-lane kernel: interval rounds walked by lane groups */
 } emme_profile_t;
 
 const char* emme_last_error(void);

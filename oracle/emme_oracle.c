@@ -247,6 +247,16 @@ static const double GK31_WK[16] = {
 
 typedef cplx (*integrand_fn)(double t, void* ctx);
 
+/* diagnostic: number of evaluated intervals per bisection depth (not thread safe; read
+ * with oracle_depth_hist after a single-threaded run) */
+static long g_depth_hist[64];
+void oracle_depth_hist(long* out64, int reset) {
+    for (int i = 0; i < 64; ++i) {
+        out64[i] = g_depth_hist[i];
+        if (reset) g_depth_hist[i] = 0;
+    }
+}
+
 /* x -> f(tan x)/cos^2 x, include/functions.h:313-316 */
 static inline cplx mapped(integrand_fn f, void* ctx, double x) {
     const double c = cos(x);
@@ -297,6 +307,10 @@ static long gk_adaptive_0_inf(integrand_fn f, void* ctx, double rel_tol, double 
         cplx integral = c_scale(K, scale);
         err = err * scale;
         ++nint;
+        {
+            int dd = (int)(log2((b - a) / (r - l)) + 0.5);
+            if (dd >= 0 && dd < 64) ++g_depth_hist[dd];
+        }
         if (fpclassify(abs_tol) == FP_ZERO) abs_tol = cabs(c_scale(integral, rel_tol));
         if (ldexp(scale, (int)max_sub) > 0.99 * (b - a) && err > abs_tol * inv_scale + prec_goal &&
             err > cabs(c_scale(integral, rel_tol)) + prec_goal) {

@@ -69,6 +69,9 @@ int oracle_solve_root(const emme_params_t* p, double gre, double gim, int nthrea
                       int recompute, double* root2, double* iterates, double* M_final,
                       long* total_intervals);
 
+/* diagnostic histogram of evaluated intervals by bisection depth (single-threaded runs) */
+void oracle_depth_hist(long* out64, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,7 @@ def main():
     pr = ctx.profile_read()
     evals = pr.integrand_evals
     s = pr.assemble_ms * 1e-3
+    print(f"union rounds {pr.union_rounds}, lane fill {pr.gk_intervals / (16.0 * max(pr.union_rounds, 1)):.3f}")
     print(f"N={a.n} batch={len(g)} reps={a.reps}: {pr.assemble_ms / a.reps / len(g):.4f} ms/matrix "
           f"({pr.assemble_ms / a.reps:.2f} ms/launch, wall {dt / a.reps * 1e3:.2f} ms), "
           f"{evals / s / 1e9:.2f} G evals/s, {evals * 900 / s / 1e12:.2f} TF-eq "
