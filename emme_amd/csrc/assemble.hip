@@ -34,9 +34,12 @@ struct AsmArgs {
     const double2* domega; // [nbatch]
     unsigned long long* intervals;  // [nbatch], atomically accumulated (may be null)
     int* status;                    // [nbatch], set non-zero on depth-cap / non-finite
+    // LIST mode: explicit (batch index, item) entries instead of the (item, blockIdx.y) grid
+    const unsigned long long* worklist;  // entry = batch << 32 | item
+    const unsigned int* worklist_count;
 };
 
-template <int PTS>
+template <int PTS, bool LIST>
 #ifndef EMME_ASM_MIN_WAVES
 #define EMME_ASM_MIN_WAVES 3
 #endif
@@ -47,8 +50,8 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
     extern __shared__ double lds_tab[];  // eta | g | b  (3N doubles) | per-group (mid, r) stack
 
     const DevParams& P = A.P;
-    const int b = blockIdx.y;
-    if (A.active && A.active[b] == 0) return;
+    int b = LIST ? 0 : blockIdx.y;
+    if (!LIST && A.active && A.active[b] == 0) return;
     const int N = P.N, dim = P.dim;
 
     for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_tab[k] = A.tab[k];
@@ -62,11 +65,20 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
     double2* stk = reinterpret_cast<double2*>(lds_tab + 3 * N + (3 * N & 1)) +
                    (threadIdx.x / GW) * MAXD;
 
-    double2* Mb = A.M + (size_t)b * dim * dim;
-    const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
-    double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
+    double2* Mb = nullptr;
+    const double2* Moldb = nullptr;
+    double2* Mpb = nullptr;
     cd rdw = mk(0.0, 0.0);
-    if (Moldb) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
+    OmegaConst oc;
+    auto bind_batch = [&]() {  // everything that depends on the batch index b
+        Mb = A.M + (size_t)b * dim * dim;
+        Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
+        Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
+        if (Moldb) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
+        oc.omega = mk(A.omega[b].x, A.omega[b].y);
+        oc.omi = -copysign(1.0, oc.omega.x);
+    };
+    if (!LIST) bind_batch();
 
     auto store = [&](int r, int c, cd v) {
         const size_t idx = (size_t)r * dim + c;
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
     };
 
     // diagonal (include/solver.h:442-443, 465-470): block 0 of each batch item
-    if (blockIdx.x == 0) {
+    if (!LIST && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
             store(i, i, mk(P.diag_a, 0.0));
             if (P.nm == 3) {
@@ -90,10 +102,6 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
         }
     }
 
-    OmegaConst oc;
-    oc.omega = mk(A.omega[b].x, A.omega[b].y);
-    oc.omi = -copysign(1.0, oc.omega.x);
-
     const int lane_in_group = threadIdx.x % GW;
     const int group = blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / GW;
     const int ngroups = gridDim.x * GROUPS_PER_BLOCK;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
 
     const double qa = 0.0, qb = M_PI / 2.0;  // include/functions.h:319 / :328
     const double inv_scale = 2. / (qb - qa);
-    const int nitems = A.npairs * P.nm;
+    const int nitems = LIST ? (int)*A.worklist_count : A.npairs * P.nm;
 
     // ---- group state ------------------------------------------------------------
     int item = group;
@@ -119,8 +127,15 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
     int bad = 0;
 
     auto load_item = [&]() {
-        const int p = item / P.nm;
-        m = item - p * P.nm;
+        int it = item;
+        if (LIST) {
+            const unsigned long long e = A.worklist[item];
+            it = (int)(e & 0xffffffffull);
+            b = (int)(e >> 32);
+            bind_batch();
+        }
+        const int p = it / P.nm;
+        m = it - p * P.nm;
         const ushort2 ij = A.pairs[p];
         i = ij.x, j = ij.y;
         dg = gtab[i] - gtab[j];
@@ -199,6 +214,11 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
                         store(j + N, i + N, v);
                     }
                 }
+                if (LIST && lane_in_group == 0) {  // the batch index changes with the item
+                    if (A.intervals) atomicAdd(&A.intervals[b], (unsigned long long)item_intervals);
+                    if (bad) A.status[b] = 1;
+                    bad = 0;
+                }
                 item += ngroups;
                 live = item < nitems;
                 if (live) load_item();
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
         }
     }
 
-    if (lane_in_group == 0) {
+    if (!LIST && lane_in_group == 0) {
         if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
         if (bad) A.status[b] = 1;
     }
@@ -233,6 +253,8 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream) {
     A.domega = (const double2*)L.domega;
     A.intervals = L.intervals;
     A.status = L.status;
+    A.worklist = nullptr;
+    A.worklist_count = nullptr;
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     const long nitems = (long)L.npairs * L.P.nm;
@@ -246,9 +268,41 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream) {
     const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
                        (size_t)groups_per_block * 40 * sizeof(double2);
     if (L.gk_points == 15)
-        hipLaunchKernelGGL(k_assemble<15>, grid, block, lds, stream, A);
+        hipLaunchKernelGGL((k_assemble<15, false>), grid, block, lds, stream, A);
     else
-        hipLaunchKernelGGL(k_assemble<31>, grid, block, lds, stream, A);
+        hipLaunchKernelGGL((k_assemble<31, false>), grid, block, lds, stream, A);
+    return hipGetLastError();
+}
+
+// Integrals the cached kernel deferred (they need intervals deeper than the cache holds):
+// recomputed whole by the lanes-are-nodes kernel from a device-side list whose length the
+// host does not know -- a fixed grid strides over it and exits at once when it is empty.
+hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
+                                const unsigned int* count, hipStream_t stream) {
+    AsmArgs A;
+    A.P = L.P;
+    A.tab = L.tab;
+    A.pairs = (const ushort2*)L.pairs;
+    A.npairs = L.npairs;
+    A.omega = (const double2*)L.omega;
+    A.active = nullptr;
+    A.M = (double2*)L.M;
+    A.Mold = (const double2*)L.Mold;
+    A.Mp = (double2*)L.Mp;
+    A.domega = (const double2*)L.domega;
+    A.intervals = L.intervals;
+    A.status = L.status;
+    A.worklist = worklist;
+    A.worklist_count = count;
+    const int gw = L.gk_points == 15 ? 16 : 32;
+    const int groups_per_block = 256 / gw;
+    dim3 grid(2048), block(256);
+    const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
+                       (size_t)groups_per_block * 40 * sizeof(double2);
+    if (L.gk_points == 15)
+        hipLaunchKernelGGL((k_assemble<15, true>), grid, block, lds, stream, A);
+    else
+        hipLaunchKernelGGL((k_assemble<31, true>), grid, block, lds, stream, A);
     return hipGetLastError();
 }
 

@@ -1,0 +1,422 @@
+// assemble_cached.hip -- batched fill from an HBM-resident cache of the omega-independent
+// node data.
+//
+// emme_device.hpp::node_data shows that, for a pair (i,j), moment m and contour sense, the
+// integrand at a quadrature node is exp(A0 + T w)(w Q1 + Q0) with A0, T, Q1, Q0 independent
+// of omega -- and of the Newton iteration.  A root search assembles the same parameter set
+// hundreds of times (23 launches x 128 omegas in the bench), so those records are computed
+// ONCE per context for every interval of the bisection tree down to depth D and kept in HBM
+// (12.8 GB for N = 256, D = 8: this is what 288 GB of HBM3E buys).  Building the whole cache
+// costs less than one assembly launch of the on-the-fly kernels.
+//
+// With the records cached nothing ties the omegas of a batch together any more: every LANE
+// is an independent worker that owns one omega and walks that omega's own adaptive tree
+// (identical decisions to the reference), fetching 15 (31) node records per interval and
+// finishing each with one complex exponential and three complex products.  No idle lanes, no
+// cross-lane reduction, summation in the reference's order.
+//   * k_node_cache   fills the cache: one 16/32-lane group per (item, interval), lane = node.
+//   * k_assemble_cached  the fill.  An integral that needs an interval deeper than D (rare:
+//     strongly damped omegas) is handed over whole, through a device-side work list, to the
+//     lanes-are-nodes kernel (assemble.hip, list mode), which recomputes it on the fly.
+#include <hip/hip_runtime.h>
+
+#include "assemble_common.hpp"
+#include "launch.hpp"
+
+namespace emme {
+
+namespace {
+
+struct NodeRec {  // one 64-byte line per (item, interval, node)
+    double2 A0, T, Q1, Q0;
+};
+
+// Which intervals are cached.  Adaptive trees of this integrand are shallow everywhere except
+// towards t -> infinity (x -> pi/2), where damped omegas force a narrow, deep refinement; so
+// the cache holds the FULL tree down to depth `dfull` plus the full SUBTREE below the
+// rightmost node of depth `rsub` (path prefix 11..1) down to depth `ddeep`.
+struct CacheGeom {
+    int dfull, rsub, ddeep;
+    __host__ __device__ int ni_full() const { return (2 << dfull) - 1; }
+    __host__ __device__ int ni_sub() const { return ddeep > dfull ? (2 << (ddeep - rsub)) - 1 : 0; }
+    __host__ __device__ int ni() const { return ni_full() + ni_sub(); }
+    // record slot of interval (depth, path), or -1 if it is not cached
+    __device__ int slot(int depth, unsigned long long path) const {
+        if (depth <= dfull) return (1 << depth) - 1 + (int)path;
+        if (depth <= ddeep) {
+            const int sd = depth - rsub;
+            if ((path >> sd) == (1ull << rsub) - 1ull)
+                return ni_full() + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
+        }
+        return -1;
+    }
+    // inverse of slot()
+    __device__ void interval(int idx, int& depth, unsigned long long& path) const {
+        if (idx < ni_full()) {
+            depth = 31 - __clz(idx + 1);
+            path = (unsigned long long)(idx + 1) - (1ull << depth);
+        } else {
+            const int k = idx - ni_full();
+            const int sd = 31 - __clz(k + 1);
+            depth = rsub + sd;
+            path = (((1ull << rsub) - 1ull) << sd) | ((unsigned long long)(k + 1) - (1ull << sd));
+        }
+    }
+};
+
+// [l, r] of interval (depth, path) with the reference's midpoint sequence
+__device__ __forceinline__ void interval_bounds(int depth, unsigned long long path, double& l,
+                                                double& r) {
+    l = 0.0;
+    r = M_PI / 2.0;
+    for (int s = depth - 1; s >= 0; --s) {
+        const double mid = (r + l) / 2;
+        if ((path >> s) & 1)
+            l = mid;
+        else
+            r = mid;
+    }
+}
+
+struct CacheArgs {
+    DevParams P;
+    const double* tab;
+    const ushort2* pairs;
+    int npairs;
+    CacheGeom geom;
+    double omi;      // class being built
+    NodeRec* recs;   // [nitems][NI][GW]
+};
+
+template <int PTS>
+__global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
+    constexpr int GW = PTS == 15 ? 16 : 32;
+    constexpr int GROUPS_PER_BLOCK = 256 / GW;
+    const DevParams& P = A.P;
+    const int N = P.N;
+    const int NI = A.geom.ni();  // cached intervals per item
+    const int lane = threadIdx.x % GW;
+    const long nitems = (long)A.npairs * P.nm;
+    const long total = nitems * NI;
+    const GkLane gk = gk_lane<PTS>(lane);
+    const double* eta = A.tab;
+    const double* gtab = A.tab + N;
+    const double* btab = A.tab + 2 * N;
+    for (long w = (long)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / GW; w < total;
+         w += (long)gridDim.x * GROUPS_PER_BLOCK) {
+        const long item = w / NI;
+        const int idx = (int)(w - item * NI);
+        const int p = (int)(item / P.nm);
+        const int m = (int)(item - (long)p * P.nm);
+        const ushort2 ij = A.pairs[p];
+        const int i = ij.x, j = ij.y;
+        const PairConst pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], gtab[i] - gtab[j]);
+        int depth;
+        unsigned long long path;
+        A.geom.interval(idx, depth, path);
+        double l, r;
+        interval_bounds(depth, path, l, r);
+        const double mid = (r + l) / 2, scale = (r - l) / 2;
+        const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
+        const NodeData d = node_data(x, P, pc, A.omi, m);
+        NodeRec rec;
+        rec.A0 = make_double2(d.A0.x, d.A0.y);
+        rec.T = make_double2(d.T.x, d.T.y);
+        rec.Q1 = make_double2(d.Q1.x, d.Q1.y);
+        rec.Q0 = make_double2(d.Q0.x, d.Q0.y);
+        A.recs[w * GW + lane] = rec;
+    }
+}
+
+struct AsmCachedArgs {
+    DevParams P;
+    const double* tab;
+    const ushort2* pairs;
+    int npairs;
+    CacheGeom geom;
+    const NodeRec* recs[2];   // per contour class (omi = +1, -1); null if not built
+    unsigned long long* worklist;   // deferred integrals: batch << 32 | item
+    unsigned int* worklist_count;
+    const int* act_idx;
+    int n_act;
+    const double2* omega;
+    double2* M;
+    const double2* Mold;
+    double2* Mp;
+    const double2* domega;
+    unsigned long long* intervals;
+    int* status;
+};
+
+#ifndef EMME_CACHED_MIN_WAVES
+#define EMME_CACHED_MIN_WAVES 3
+#endif
+
+template <int PTS>
+__global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(AsmCachedArgs A) {
+    constexpr int GW = PTS == 15 ? 16 : 32;
+    constexpr int H = (PTS + 1) / 2;
+    constexpr int GROUPS_PER_BLOCK = 256 / GW;
+    extern __shared__ double lds_raw[];  // eta | g | b
+
+    const DevParams& P = A.P;
+    const int N = P.N, dim = P.dim;
+    for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_raw[k] = A.tab[k];
+    __syncthreads();
+    const double* eta = lds_raw;
+    const double* gtab = lds_raw + N;
+    const double* btab = lds_raw + 2 * N;
+    const int group_in_block = threadIdx.x / GW;
+    const int lane = threadIdx.x % GW;
+
+    // lane -> (omega slot, item stream).  A chunk holds up to GW omegas; when it holds fewer
+    // (small batches, the tail of a root search) the spare lanes take further item streams of
+    // the same omegas, so a single omega still fills all lanes.
+    const int n_in_chunk = min(GW, A.n_act - (int)blockIdx.y * GW);
+    int n_eff = 1;
+    while (n_eff < n_in_chunk) n_eff <<= 1;
+    const int nsub = GW / n_eff;
+    const int wslot = lane % n_eff, sub = lane / n_eff;
+    const bool has_w = wslot < n_in_chunk;
+    const int b = has_w ? A.act_idx[blockIdx.y * GW + wslot] : 0;
+    cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
+    if (has_w) {
+        omega = mk(A.omega[b].x, A.omega[b].y);
+        if (A.Mold) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
+    }
+    const NodeRec* recs = A.recs[-copysign(1.0, omega.x) > 0.0 ? 0 : 1];
+    double2* Mb = A.M + (size_t)b * dim * dim;
+    const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
+    double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
+    auto store = [&](int r, int c, cd v) {
+        const size_t idx = (size_t)r * dim + c;
+        Mb[idx] = make_double2(v.x, v.y);
+        if (Moldb) {
+            const double2 o = Moldb[idx];
+            const cd d = (v - mk(o.x, o.y)) * rdw;
+            Mpb[idx] = make_double2(d.x, d.y);
+        }
+    };
+    if (blockIdx.x == 0 && has_w && sub == 0) {  // diagonal (include/solver.h:442-443, 465-470)
+        for (int i = group_in_block; i < N; i += GROUPS_PER_BLOCK) {
+            store(i, i, mk(P.diag_a, 0.0));
+            if (P.nm == 3) {
+                store(i, i + N, mk(0.0, 0.0));
+                store(i + N, i, mk(0.0, 0.0));
+                store(i + N, i + N, mk(P.diag_d * btab[i], 0.0));
+            }
+        }
+    }
+
+    const double* WK = PTS == 15 ? kWk15 : kWk31;
+    const double* WG = PTS == 15 ? kWg15 : kWg31;
+    const double qb_minus_qa = M_PI / 2.0;
+    const double inv_scale = 2. / qb_minus_qa;
+    const int nitems = A.npairs * P.nm;
+    const int NI = A.geom.ni();
+    const int worker = (blockIdx.x * GROUPS_PER_BLOCK + group_in_block) * nsub + sub;
+    const int nworkers = gridDim.x * GROUPS_PER_BLOCK * nsub;
+
+    // ---- lane state: an independent walk of this omega's tree over the item stream --------
+    int item = worker;
+    bool live = has_w && item < nitems;
+    int i = 0, j = 0, m = 0;
+    double de = 0.0, dg = 0.0;
+    int depth = 0;
+    unsigned long long path = 0;
+    double abs_tol = 0.0;
+    cd sum = mk(0.0, 0.0);
+    unsigned long long my_intervals = 0;
+    int item_intervals = 0, bad = 0;
+
+    auto load_item = [&]() {
+        const int p = item / P.nm;
+        m = item - p * P.nm;
+        const ushort2 ij = A.pairs[p];
+        i = ij.x, j = ij.y;
+        dg = gtab[i] - gtab[j];
+        de = eta[i] - eta[j];
+        depth = 0, path = 0, abs_tol = 0.0, item_intervals = 0;
+        sum = mk(0.0, 0.0);
+    };
+    auto next_item = [&]() {
+        item += nworkers;
+        live = item < nitems;
+        if (live) load_item();
+    };
+    if (live) load_item();
+
+    while (live) {
+        const int cslot = A.geom.slot(depth, path);
+        if (cslot < 0) {
+            // outside the cache: hand the whole integral to the on-the-fly kernel
+            const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+            A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
+            my_intervals -= (unsigned long long)item_intervals;  // it will be recounted there
+            next_item();
+            continue;
+        }
+        // scale = (r - l) / 2 of interval (depth, path); the records hold everything else
+        double l, r;
+        interval_bounds(depth, path, l, r);
+        const double scale = (r - l) / 2;
+        // ---- 15 (31) records of my interval, reference summation order -----------------
+        // (include/functions.h:186-201: centre, then f(+x_q) + f(-x_q) for q = 1..H-1)
+        const NodeRec* rp = recs + ((long)item * NI + cslot) * GW;
+        cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
+        // visiting order s = 0..PTS-1: centre, +x_1, -x_1, +x_2, -x_2, ...
+        auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
+        auto proc = [&](const NodeRec& rec, int s) {
+            NodeData d;
+            d.A0 = mk(rec.A0.x, rec.A0.y);
+            d.T = mk(rec.T.x, rec.T.y);
+            d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+            d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+            const cd f = node_eval(d, omega);
+            if (s & 1) {
+                fplus = f;
+            } else {
+                const int q = s >> 1;
+                const cd fs = s == 0 ? f : fplus + f;
+                K = K + WK[q] * fs;
+                if ((q & 1) == 0) G = G + WG[q >> 1] * fs;
+            }
+        };
+        // three record buffers rotate so that two 64-byte loads are always in flight while a
+        // third record is being evaluated (each record is one cache line of its own)
+        NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
+#pragma unroll 1
+        for (int s = 0; s < PTS; s += 3) {
+            if (s + 2 < PTS) r2 = rp[node_of(s + 2)];
+            proc(r0, s);
+            if (s + 3 < PTS) r0 = rp[node_of(s + 3)];
+            if (s + 1 < PTS) proc(r1, s + 1);
+            if (s + 4 < PTS) r1 = rp[node_of(s + 4)];
+            if (s + 2 < PTS) proc(r2, s + 2);
+        }
+        ++my_intervals;
+        ++item_intervals;
+        // include/functions.h:203-208, 231-247
+        const double dKx = K.x - G.x, dKy = K.y - G.y;
+        const double absK = sqrt(fma(K.x, K.x, K.y * K.y));
+        double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
+        const cd integral = mk(K.x * scale, K.y * scale);
+        err *= scale;
+        const double rel_abs = P.rel_tol * (absK * scale);
+        if (abs_tol == 0.0) abs_tol = rel_abs;
+        bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
+                     err > rel_abs + P.prec_goal;
+        if (split && item_intervals >= (1 << 18)) {
+            split = false;
+            bad = 1;
+        }
+        if (split) {
+            ++depth;
+            path <<= 1;
+        } else {
+            sum = sum + integral;
+            ++path;
+            while (depth > 0 && !(path & 1)) {
+                path >>= 1;
+                --depth;
+            }
+            if (depth == 0) {
+                cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));
+                if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+                kap = kap + kappa_e(m, P, de, dg, omega);
+                if (m == 0) {
+                    const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
+                    store(i, j, v);
+                    store(j, i, v);
+                } else if (m == 1) {
+                    const cd v = P.dx * kap;
+                    store(i, j + N, v);
+                    store(j, i + N, -v);
+                    store(i + N, j, -v);
+                    store(j + N, i, v);
+                } else {
+                    const cd v = P.dx * kap;
+                    store(i + N, j + N, v);
+                    store(j + N, i + N, v);
+                }
+                next_item();
+            }
+        }
+    }
+
+    if (has_w) {
+        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
+        if (bad) A.status[b] = 1;
+    }
+}
+
+}  // namespace
+
+static CacheGeom make_geom(const NodeCacheGeom& g) {
+    CacheGeom c;
+    c.dfull = g.dfull, c.rsub = g.rsub, c.ddeep = g.ddeep;
+    return c;
+}
+
+size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g) {
+    const int gw = gk_points == 15 ? 16 : 32;
+    return (size_t)nitems * (size_t)make_geom(g).ni() * gw * sizeof(NodeRec);
+}
+
+hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, double omi, void* recs,
+                             hipStream_t stream) {
+    CacheArgs A;
+    A.P = L.P;
+    A.tab = L.tab;
+    A.pairs = (const ushort2*)L.pairs;
+    A.npairs = L.npairs;
+    A.geom = make_geom(g);
+    A.omi = omi;
+    A.recs = (NodeRec*)recs;
+    dim3 grid(256 * 32), block(256);
+    if (L.gk_points == 15)
+        hipLaunchKernelGGL(k_node_cache<15>, grid, block, 0, stream, A);
+    else
+        hipLaunchKernelGGL(k_node_cache<31>, grid, block, 0, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
+                                  unsigned long long* worklist, unsigned int* worklist_count,
+                                  const int* act_idx, int n_act, hipStream_t stream) {
+    AsmCachedArgs A;
+    A.P = L.P;
+    A.tab = L.tab;
+    A.pairs = (const ushort2*)L.pairs;
+    A.npairs = L.npairs;
+    A.geom = make_geom(g);
+    for (int c = 0; c < 2; ++c) A.recs[c] = (const NodeRec*)recs[c];
+    A.worklist = worklist;
+    A.worklist_count = worklist_count;
+    A.act_idx = act_idx;
+    A.n_act = n_act;
+    A.omega = (const double2*)L.omega;
+    A.M = (double2*)L.M;
+    A.Mold = (const double2*)L.Mold;
+    A.Mp = (double2*)L.Mp;
+    A.domega = (const double2*)L.domega;
+    A.intervals = L.intervals;
+    A.status = L.status;
+    const int gw = L.gk_points == 15 ? 16 : 32;
+    const int groups_per_block = 256 / gw;
+    const int chunks = (n_act + gw - 1) / gw;
+    const long nitems = (long)L.npairs * L.P.nm;
+    long want_groups = (nitems + L.items_per_group - 1) / L.items_per_group;
+    long gx = (want_groups + groups_per_block - 1) / groups_per_block;
+    if (gx < 1) gx = 1;
+    if (gx > 65535) gx = 65535;
+    dim3 grid((unsigned)gx, (unsigned)chunks), block(256);
+    const size_t lds = (size_t)3 * L.P.N * sizeof(double);
+    if (L.gk_points == 15)
+        hipLaunchKernelGGL(k_assemble_cached<15>, grid, block, lds, stream, A);
+    else
+        hipLaunchKernelGGL(k_assemble_cached<31>, grid, block, lds, stream, A);
+    return hipGetLastError();
+}
+
+}  // namespace emme

@@ -68,6 +68,14 @@ struct emme_ctx {
     int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
+    // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
+    int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
+    NodeCacheGeom cache_geom{0, 0, 0};
+    void* d_recs[2] = {nullptr, nullptr};
+    unsigned long long* d_worklist = nullptr;  // integrals deferred to the on-the-fly kernel
+    unsigned int* d_worklist_count = nullptr;
+    size_t worklist_cap = 0;
+    double cache_budget_gb = 64.0;  // both classes together
     int mat_cap = 0;  // matrices per set
     double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
     double* d_iterates = nullptr;
@@ -201,12 +209,55 @@ int items_per_group_for(const emme_ctx* c, long units) {
     return (int)ipg;
 }
 
+// Make sure the node cache of contour class `cls` (0: omi=+1, 1: omi=-1) exists.
+// Returns false (and disables the cache) if it cannot be allocated within the budget.
+bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
+    if (c->cache_depth == -2) return false;
+    const long nitems = (long)c->npairs * c->nm;
+    if (c->cache_depth == -1) {
+        // largest geometry within the budget: deep right-hand subtree first (that is where
+        // damped omegas refine), then the depth of the full tree
+        const double per_class = c->cache_budget_gb * 0.5 * (1 << 30);
+        static const NodeCacheGeom options[] = {{7, 5, 13}, {6, 5, 13}, {6, 5, 12}, {6, 5, 11},
+                                                {5, 4, 10}, {5, 4, 9},  {4, 4, 4},  {3, 3, 3}};
+        bool found = false;
+        for (const auto& g : options) {
+            if ((double)node_cache_bytes(L.gk_points, nitems, g) <= per_class) {
+                c->cache_geom = g;
+                found = true;
+                break;
+            }
+        }
+        if (!found) {
+            c->cache_depth = -2;
+            return false;
+        }
+        c->cache_depth = c->cache_geom.dfull;
+    }
+    if (c->d_recs[cls]) return true;
+    const size_t bytes = node_cache_bytes(L.gk_points, nitems, c->cache_geom);
+    if (hipMalloc(&c->d_recs[cls], bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        c->d_recs[cls] = nullptr;
+        c->cache_depth = -2;  // fall back to the on-the-fly kernels for good
+        return false;
+    }
+    ScopedSpan s(c, K_OTHER);
+    if (launch_node_cache(L, c->cache_geom, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->stream) !=
+        hipSuccess) {
+        c->cache_depth = -2;
+        return false;
+    }
+    return true;
+}
+
 // host_active: which of the nbatch items to assemble (null = all).  Batches of wl_min or
 // more items go through the omega-lane kernel, which shares the omega-independent node
 // data between items; smaller ones through the lanes-are-nodes kernel.
 int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
                 const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
-                const double* d_domega, const unsigned long long* cost = nullptr) {
+                const double* d_domega, const unsigned long long* cost = nullptr,
+                const double* host_omega = nullptr) {
     AssembleLaunch L;
     L.P = c->P;
     L.gk_points = c->p.integration_start_points;
@@ -235,7 +286,35 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     // similar cost (interval count of their previous assembly) together.
     if (cost)
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    if (n_act >= c->wl_min) {
+    // contour classes present among the omegas (needs their host values)
+    bool use_cache = host_omega != nullptr && c->cache_depth != -2;
+    if (use_cache) {
+        bool need[2] = {false, false};
+        for (int b : idx) need[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1] = true;
+        for (int k = 0; k < 2 && use_cache; ++k)
+            if (need[k]) use_cache = ensure_node_cache(c, L, k);
+    }
+    if (use_cache) {
+        // work list for integrals that outgrow the cache (worst case: every one of them)
+        const size_t need = (size_t)c->npairs * c->nm * (size_t)nbatch;
+        if (need > c->worklist_cap) {
+            if (c->d_worklist) (void)hipFree(c->d_worklist);
+            c->d_worklist = nullptr;
+            HIP_TRY(hipMalloc((void**)&c->d_worklist, need * sizeof(unsigned long long)));
+            c->worklist_cap = need;
+        }
+        if (!c->d_worklist_count) HIP_TRY(hipMalloc((void**)&c->d_worklist_count, sizeof(unsigned int)));
+    }
+    if (use_cache) {
+        const int gw = L.gk_points == 15 ? 16 : 32;
+        L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
+        HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
+        ScopedSpan s(c, K_ASM);
+        HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_worklist, c->d_worklist_count,
+                                       c->d_actidx, n_act, c->stream));
+        HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, c->stream));
+    } else if (n_act >= c->wl_min) {
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
         HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
@@ -288,6 +367,7 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->p = *p;
     c->device = device;
     if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
+    if (const char* e = std::getenv("EMME_NODE_CACHE_GB")) c->cache_budget_gb = std::atof(e);
     const int N = p->npoints;
     c->N = N;
     const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
@@ -351,6 +431,8 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
         F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_M), F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
+    for (int k = 0; k < 2; ++k) F(c->d_recs[k]);
+    F(c->d_worklist), F(c->d_worklist_count);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     delete c;
@@ -403,7 +485,7 @@ int emme_assemble_batch(emme_ctx_t* c, const double* omega, int nbatch, double* 
     HIP_TRY(hipMemcpyAsync(c->d_omega, omega, sizeof(double) * 2 * nbatch, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_intervals, 0, sizeof(unsigned long long) * nbatch, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * nbatch, c->stream));
-    rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, dM, nullptr, nullptr, nullptr);
+    rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, dM, nullptr, nullptr, nullptr, nullptr, omega);
     if (rc) return rc;
     if (!dev_out)
         HIP_TRY(hipMemcpyAsync(M, dM, mat_doubles(c) * sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
@@ -511,7 +593,10 @@ int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nba
         HIP_TRY(launch_newton_update(nbatch, c->d_tr, c->d_omega, c->d_domega, nullptr, nullptr,
                                      c->d_info, 0.0, nullptr, 0, 0, c->stream));
     }
-    rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, dM, c->d_Mold, dMp, c->d_domega);
+    std::vector<double> h_w(2 * (size_t)nbatch);
+    HIP_TRY(hipMemcpyAsync(h_w.data(), c->d_omega, sizeof(double) * 2 * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, dM, c->d_Mold, dMp, c->d_domega, nullptr, h_w.data());
     if (rc) return rc;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(M, dM, mbytes, hipMemcpyDeviceToHost, c->stream));
@@ -574,6 +659,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     HIP_TRY(hipMemcpyAsync(c->d_omega, w0.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_domega, dw.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     std::vector<int> act(n, 1);
+    std::vector<double> h_w(2 * (size_t)n);
     std::vector<unsigned long long> iv_prev(n, 0), iv_now(n, 0), cost(n, 0), iv_prev_dbg(n, 0);
     auto refresh_cost = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(iv_now.data(), c->d_intervals, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
@@ -584,13 +670,13 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         }
         return EMME_OK;
     };
-    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_Mold, nullptr, nullptr, nullptr);
+    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_Mold, nullptr, nullptr, nullptr, nullptr, w0.data());
     if (rc) return rc;
     rc = refresh_cost();  // synchronises; the first fill's interval counts order the second
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_omega, w1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
-                     cost.data());
+                     cost.data(), w1.data());
     if (rc) return rc;
 
     rc = refresh_cost();
@@ -610,8 +696,10 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             HIP_TRY(launch_newton_update(n, c->d_tr, c->d_omega, c->d_domega, c->d_active, c->d_iters,
                                          c->d_info, tol, c->d_iterates, j, stride, c->stream));
         }
+        HIP_TRY(hipMemcpyAsync(h_w.data(), c->d_omega, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
-                         cost.data());
+                         cost.data(), h_w.data());
         if (rc) return rc;
         {
             ScopedSpan s(c, K_OTHER);

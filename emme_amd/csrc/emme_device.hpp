@@ -59,29 +59,37 @@ __device__ __forceinline__ cd rcp(cd a) {
     return cd{a.x * d, -(a.y * d)};
 }
 
+// A floating-point literal pinned to a scalar register pair: the polynomial kernels below
+// then compile to one v_fma_f64 per Horner step with the coefficient as an SGPR operand,
+// instead of a VGPR copy + v_fmac per step (and ~40 VGPRs of hoisted coefficients).
+__device__ __forceinline__ double sreg(double c) {
+    asm("" : "+s"(c));
+    return c;
+}
+
 // sin and cos of a moderate argument (|x| < ~1e9): three-term Cody-Waite reduction by pi/2
 // carried by FMAs (the first FMA x - n*C1 is exact by cancellation), then the classical
 // degree-13 / degree-14 minimax kernels on [-pi/4, pi/4].  ~1 ulp, no slow path: the
 // phase of the integrand's exponent stays far below 1e9 wherever the clamp lets it live.
 __device__ __forceinline__ void fsincos(double x, double& s, double& c) {
-    const double n = rint(x * 0.63661977236758134308);  // 2/pi
-    double r = fma(-n, 1.5707963267948965580e+00, x);
-    r = fma(-n, 6.1232339957367660359e-17, r);
-    r = fma(-n, -1.4973849048591698329e-33, r);
+    const double n = rint(x * sreg(0.63661977236758134308));  // 2/pi
+    double r = fma(-n, sreg(1.5707963267948965580e+00), x);
+    r = fma(-n, sreg(6.1232339957367660359e-17), r);
+    r = fma(-n, sreg(-1.4973849048591698329e-33), r);
     const double z = r * r;
     // sin kernel
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double ps = fma(z, sreg(1.58969099521155010221e-10), sreg(-2.50507602534068634195e-08));
+    ps = fma(z, ps, sreg(2.75573137070700676789e-06));
+    ps = fma(z, ps, sreg(-1.98412698298579493134e-04));
+    ps = fma(z, ps, sreg(8.33333333332248946124e-03));
+    ps = fma(z, ps, sreg(-1.66666666666666324348e-01));
     const double sn = fma(r * z, ps, r);
     // cos kernel
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double pc = fma(z, sreg(-1.13596475577881948265e-11), sreg(2.08757232129817482790e-09));
+    pc = fma(z, pc, sreg(-2.75573143513906633035e-07));
+    pc = fma(z, pc, sreg(2.48015872894767294178e-05));
+    pc = fma(z, pc, sreg(-1.38888888888741095749e-03));
+    pc = fma(z, pc, sreg(4.16666666666666019037e-02));
     const double hz = 0.5 * z;
     const double wv = 1.0 - hz;
     const double cs = wv + (((1.0 - wv) - hz) + z * (z * pc));
@@ -95,20 +103,20 @@ __device__ __forceinline__ void fsincos(double x, double& s, double& c) {
 // exp(x) for x in the clamp's range [-40, 709]: x = k ln2 + r, degree-13 Taylor polynomial
 // on |r| <= ln2/2 (truncation 4e-18) evaluated by Horner, scaled with ldexp.
 __device__ __forceinline__ double fexp(double x) {
-    const double k = rint(x * 1.4426950408889634074);
-    double r = fma(-k, 6.93147180369123816490e-01, x);
-    r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;           // 1/13!
-    p = fma(p, r, 2.0876756987868100e-09);       // 1/12!
-    p = fma(p, r, 2.5052108385441720e-08);       // 1/11!
-    p = fma(p, r, 2.7557319223985888e-07);       // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);       // 1/9!
-    p = fma(p, r, 2.4801587301587302e-05);       // 1/8!
-    p = fma(p, r, 1.9841269841269841e-04);       // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);       // 1/6!
-    p = fma(p, r, 8.3333333333333332e-03);       // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);       // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);       // 1/3!
+    const double k = rint(x * sreg(1.4426950408889634074));
+    double r = fma(-k, sreg(6.93147180369123816490e-01), x);
+    r = fma(-k, sreg(1.90821492927058770002e-10), r);
+    double p = sreg(1.6059043836821613e-10);           // 1/13!
+    p = fma(p, r, sreg(2.0876756987868100e-09));       // 1/12!
+    p = fma(p, r, sreg(2.5052108385441720e-08));       // 1/11!
+    p = fma(p, r, sreg(2.7557319223985888e-07));       // 1/10!
+    p = fma(p, r, sreg(2.7557319223985893e-06));       // 1/9!
+    p = fma(p, r, sreg(2.4801587301587302e-05));       // 1/8!
+    p = fma(p, r, sreg(1.9841269841269841e-04));       // 1/7!
+    p = fma(p, r, sreg(1.3888888888888889e-03));       // 1/6!
+    p = fma(p, r, sreg(8.3333333333333332e-03));       // 1/5!
+    p = fma(p, r, sreg(4.1666666666666664e-02));       // 1/4!
+    p = fma(p, r, sreg(1.6666666666666666e-01));       // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

@@ -30,6 +30,21 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream);
 hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n_act,
                               hipStream_t stream);
 
+// HBM cache of the omega-independent node records (assemble_cached.hip): full bisection tree
+// to depth dfull + the subtree under the rightmost depth-rsub node down to depth ddeep
+struct NodeCacheGeom {
+    int dfull, rsub, ddeep;
+};
+size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g);
+hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, double omi, void* recs,
+                             hipStream_t stream);
+hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
+                                  unsigned long long* worklist, unsigned int* worklist_count,
+                                  const int* act_idx, int n_act, hipStream_t stream);
+// integrals deferred by the cached kernel, recomputed by the lanes-are-nodes kernel
+hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
+                                const unsigned int* count, hipStream_t stream);
+
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
                               double* tr /*2*nbatch*/, int* info, hipStream_t stream);
