@@ -33,20 +33,29 @@ struct NodeRec {  // one 64-byte line per (item, interval, node)
 
 // Which intervals are cached.  Adaptive trees of this integrand are shallow everywhere except
 // towards t -> infinity (x -> pi/2), where damped omegas force a narrow, deep refinement; so
-// the cache holds the FULL tree down to depth `dfull` plus the full SUBTREE below the
-// rightmost node of depth `rsub` (path prefix 11..1) down to depth `ddeep`.
+// the cache holds the FULL tree down to depth `dfull` plus up to two full SUBTREES below
+// rightmost nodes (path prefix 11..1 of length rsub[k]) down to depth ddeep[k]: a wide one
+// for ordinary damped roots and a narrow, deeper one for strongly damped omegas.
 struct CacheGeom {
-    int dfull, rsub, ddeep;
+    int dfull;            // full tree down to this depth
+    int rsub[2], ddeep[2];  // subtree under the rightmost depth-rsub node down to depth ddeep
     __host__ __device__ int ni_full() const { return (2 << dfull) - 1; }
-    __host__ __device__ int ni_sub() const { return ddeep > dfull ? (2 << (ddeep - rsub)) - 1 : 0; }
-    __host__ __device__ int ni() const { return ni_full() + ni_sub(); }
+    __host__ __device__ int ni_sub(int k) const {
+        return ddeep[k] > rsub[k] ? (2 << (ddeep[k] - rsub[k])) - 1 : 0;
+    }
+    __host__ __device__ int ni() const { return ni_full() + ni_sub(0) + ni_sub(1); }
     // record slot of interval (depth, path), or -1 if it is not cached
     __device__ int slot(int depth, unsigned long long path) const {
         if (depth <= dfull) return (1 << depth) - 1 + (int)path;
-        if (depth <= ddeep) {
-            const int sd = depth - rsub;
-            if ((path >> sd) == (1ull << rsub) - 1ull)
-                return ni_full() + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
+        int base = ni_full();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (depth <= ddeep[k] && depth >= rsub[k]) {
+                const int sd = depth - rsub[k];
+                if ((path >> sd) == (1ull << rsub[k]) - 1ull)
+                    return base + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
+            }
+            base += ni_sub(k);
         }
         return -1;
     }
@@ -55,12 +64,13 @@ struct CacheGeom {
         if (idx < ni_full()) {
             depth = 31 - __clz(idx + 1);
             path = (unsigned long long)(idx + 1) - (1ull << depth);
-        } else {
-            const int k = idx - ni_full();
-            const int sd = 31 - __clz(k + 1);
-            depth = rsub + sd;
-            path = (((1ull << rsub) - 1ull) << sd) | ((unsigned long long)(k + 1) - (1ull << sd));
+            return;
         }
+        int k = 0, rel = idx - ni_full();
+        if (rel >= ni_sub(0)) rel -= ni_sub(0), k = 1;
+        const int sd = 31 - __clz(rel + 1);
+        depth = rsub[k] + sd;
+        path = (((1ull << rsub[k]) - 1ull) << sd) | ((unsigned long long)(rel + 1) - (1ull << sd));
     }
 };
 
@@ -86,6 +96,7 @@ struct CacheArgs {
     CacheGeom geom;
     double omi;      // class being built
     NodeRec* recs;   // [nitems][NI][GW]
+    double* scale;   // [NI] half-width (r - l)/2 of every cached interval
 };
 
 template <int PTS>
@@ -125,6 +136,7 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
         rec.Q1 = make_double2(d.Q1.x, d.Q1.y);
         rec.Q0 = make_double2(d.Q0.x, d.Q0.y);
         A.recs[w * GW + lane] = rec;
+        if (item == 0 && lane == 0) A.scale[idx] = scale;
     }
 }
 
@@ -135,6 +147,7 @@ struct AsmCachedArgs {
     int npairs;
     CacheGeom geom;
     const NodeRec* recs[2];   // per contour class (omi = +1, -1); null if not built
+    const double* scale;      // [NI]
     unsigned long long* worklist;   // deferred integrals: batch << 32 | item
     unsigned int* worklist_count;
     const int* act_idx;
@@ -210,136 +223,133 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
 
     const double* WK = PTS == 15 ? kWk15 : kWk31;
     const double* WG = PTS == 15 ? kWg15 : kWg31;
-    const double qb_minus_qa = M_PI / 2.0;
-    const double inv_scale = 2. / qb_minus_qa;
+    const double inv_scale = 2. / (M_PI / 2.0);
     const int nitems = A.npairs * P.nm;
     const int NI = A.geom.ni();
+    const double* scale_tab = lds_raw + 3 * N;  // staged below
+    for (int k = threadIdx.x; k < NI; k += blockDim.x) lds_raw[3 * N + k] = A.scale[k];
+    __syncthreads();
     const int worker = (blockIdx.x * GROUPS_PER_BLOCK + group_in_block) * nsub + sub;
     const int nworkers = gridDim.x * GROUPS_PER_BLOCK * nsub;
 
-    // ---- lane state: an independent walk of this omega's tree over the item stream --------
-    int item = worker;
-    bool live = has_w && item < nitems;
-    int i = 0, j = 0, m = 0;
-    double de = 0.0, dg = 0.0;
-    int depth = 0;
-    unsigned long long path = 0;
-    double abs_tol = 0.0;
-    cd sum = mk(0.0, 0.0);
     unsigned long long my_intervals = 0;
-    int item_intervals = 0, bad = 0;
+    int bad = 0;
+    // Item loop: the lanes of a wave take their next items together and walk their own trees
+    // until every lane has finished its integral (lanes that finish early wait: the omegas of
+    // a chunk are sorted by cost, so their trees have similar sizes); the scatter of the
+    // results then runs once for all lanes instead of diverging on every interval.
+    for (int item = worker; __ballot(has_w && item < nitems) != 0ull; item += nworkers) {
+        const bool mine = has_w && item < nitems;
+        int i = 0, j = 0, m = 0;
+        if (mine) {
+            const int p = item / P.nm;
+            m = item - p * P.nm;
+            const ushort2 ij = A.pairs[p];
+            i = ij.x, j = ij.y;
+        }
+        int depth = 0;
+        unsigned long long path = 0;
+        double abs_tol = 0.0;
+        cd sum = mk(0.0, 0.0);
+        int item_intervals = 0;
+        bool walking = mine, deferred = false;
+        const NodeRec* ibase = recs + (long)item * NI * GW;
 
-    auto load_item = [&]() {
-        const int p = item / P.nm;
-        m = item - p * P.nm;
-        const ushort2 ij = A.pairs[p];
-        i = ij.x, j = ij.y;
-        dg = gtab[i] - gtab[j];
-        de = eta[i] - eta[j];
-        depth = 0, path = 0, abs_tol = 0.0, item_intervals = 0;
-        sum = mk(0.0, 0.0);
-    };
-    auto next_item = [&]() {
-        item += nworkers;
-        live = item < nitems;
-        if (live) load_item();
-    };
-    if (live) load_item();
-
-    while (live) {
-        const int cslot = A.geom.slot(depth, path);
-        if (cslot < 0) {
-            // outside the cache: hand the whole integral to the on-the-fly kernel
-            const unsigned int slot = atomicAdd(A.worklist_count, 1u);
-            A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
-            my_intervals -= (unsigned long long)item_intervals;  // it will be recounted there
-            next_item();
-            continue;
-        }
-        // scale = (r - l) / 2 of interval (depth, path); the records hold everything else
-        double l, r;
-        interval_bounds(depth, path, l, r);
-        const double scale = (r - l) / 2;
-        // ---- 15 (31) records of my interval, reference summation order -----------------
-        // (include/functions.h:186-201: centre, then f(+x_q) + f(-x_q) for q = 1..H-1)
-        const NodeRec* rp = recs + ((long)item * NI + cslot) * GW;
-        cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
-        // visiting order s = 0..PTS-1: centre, +x_1, -x_1, +x_2, -x_2, ...
-        auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
-        auto proc = [&](const NodeRec& rec, int s) {
-            NodeData d;
-            d.A0 = mk(rec.A0.x, rec.A0.y);
-            d.T = mk(rec.T.x, rec.T.y);
-            d.Q1 = mk(rec.Q1.x, rec.Q1.y);
-            d.Q0 = mk(rec.Q0.x, rec.Q0.y);
-            const cd f = node_eval(d, omega);
-            if (s & 1) {
-                fplus = f;
-            } else {
-                const int q = s >> 1;
-                const cd fs = s == 0 ? f : fplus + f;
-                K = K + WK[q] * fs;
-                if ((q & 1) == 0) G = G + WG[q >> 1] * fs;
+        while (walking) {
+            const int cslot = A.geom.slot(depth, path);
+            if (cslot < 0) {
+                // outside the cache: hand the whole integral to the on-the-fly kernel
+                const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+                A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
+                deferred = true;
+                walking = false;
+                continue;
             }
-        };
-        // three record buffers rotate so that two 64-byte loads are always in flight while a
-        // third record is being evaluated (each record is one cache line of its own)
-        NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
-#pragma unroll 1
-        for (int s = 0; s < PTS; s += 3) {
-            if (s + 2 < PTS) r2 = rp[node_of(s + 2)];
-            proc(r0, s);
-            if (s + 3 < PTS) r0 = rp[node_of(s + 3)];
-            if (s + 1 < PTS) proc(r1, s + 1);
-            if (s + 4 < PTS) r1 = rp[node_of(s + 4)];
-            if (s + 2 < PTS) proc(r2, s + 2);
-        }
-        ++my_intervals;
-        ++item_intervals;
-        // include/functions.h:203-208, 231-247
-        const double dKx = K.x - G.x, dKy = K.y - G.y;
-        const double absK = sqrt(fma(K.x, K.x, K.y * K.y));
-        double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
-        const cd integral = mk(K.x * scale, K.y * scale);
-        err *= scale;
-        const double rel_abs = P.rel_tol * (absK * scale);
-        if (abs_tol == 0.0) abs_tol = rel_abs;
-        bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
-                     err > rel_abs + P.prec_goal;
-        if (split && item_intervals >= (1 << 18)) {
-            split = false;
-            bad = 1;
-        }
-        if (split) {
-            ++depth;
-            path <<= 1;
-        } else {
-            sum = sum + integral;
-            ++path;
-            while (depth > 0 && !(path & 1)) {
-                path >>= 1;
-                --depth;
-            }
-            if (depth == 0) {
-                cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));
-                if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
-                kap = kap + kappa_e(m, P, de, dg, omega);
-                if (m == 0) {
-                    const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
-                    store(i, j, v);
-                    store(j, i, v);
-                } else if (m == 1) {
-                    const cd v = P.dx * kap;
-                    store(i, j + N, v);
-                    store(j, i + N, -v);
-                    store(i + N, j, -v);
-                    store(j + N, i, v);
+            const double scale = scale_tab[cslot];
+            // ---- 15 (31) records of my interval, reference summation order -------------
+            // (include/functions.h:186-201: centre, then f(+x_q) + f(-x_q) for q = 1..H-1)
+            const NodeRec* rp = ibase + (long)cslot * GW;
+            cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
+            // visiting order s = 0..PTS-1: centre, +x_1, -x_1, +x_2, -x_2, ...
+            auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
+            auto proc = [&](const NodeRec& rec, int s) {
+                NodeData d;
+                d.A0 = mk(rec.A0.x, rec.A0.y);
+                d.T = mk(rec.T.x, rec.T.y);
+                d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+                d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+                const cd f = node_eval(d, omega);
+                if (s & 1) {
+                    fplus = f;
                 } else {
-                    const cd v = P.dx * kap;
-                    store(i + N, j + N, v);
-                    store(j + N, i + N, v);
+                    const int q = s >> 1;
+                    const cd fs = s == 0 ? f : fplus + f;
+                    K = K + WK[q] * fs;
+                    if ((q & 1) == 0) G = G + WG[q >> 1] * fs;
                 }
-                next_item();
+            };
+            // three record buffers rotate so that two 64-byte loads are always in flight
+            // while a third record is being evaluated (each record is one cache line)
+            NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
+#pragma unroll 1
+            for (int s = 0; s < PTS; s += 3) {
+                if (s + 2 < PTS) r2 = rp[node_of(s + 2)];
+                proc(r0, s);
+                if (s + 3 < PTS) r0 = rp[node_of(s + 3)];
+                if (s + 1 < PTS) proc(r1, s + 1);
+                if (s + 4 < PTS) r1 = rp[node_of(s + 4)];
+                if (s + 2 < PTS) proc(r2, s + 2);
+            }
+            ++item_intervals;
+            // include/functions.h:203-208, 231-247
+            const double dKx = K.x - G.x, dKy = K.y - G.y;
+            const double absK = sqrt(fma(K.x, K.x, K.y * K.y));
+            double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
+            const cd integral = mk(K.x * scale, K.y * scale);
+            err *= scale;
+            const double rel_abs = P.rel_tol * (absK * scale);
+            if (abs_tol == 0.0) abs_tol = rel_abs;
+            bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
+                         err > rel_abs + P.prec_goal;
+            if (split && item_intervals >= (1 << 18)) {
+                split = false;
+                bad = 1;
+            }
+            if (split) {
+                ++depth;
+                path <<= 1;
+            } else {
+                sum = sum + integral;
+                ++path;
+                // strip trailing zeros: up to the first ancestor that is a left child
+                const int tz = min(depth, (int)__builtin_ctzll(path | (1ull << 63)));
+                path >>= tz;
+                depth -= tz;
+                walking = depth != 0;
+            }
+        }
+
+        // ---- results of this round of items, all lanes together -------------------------
+        if (mine && !deferred) {
+            my_intervals += (unsigned long long)item_intervals;
+            const double dg = gtab[i] - gtab[j], de = eta[i] - eta[j];
+            cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));  // -i pref sum, Parameters.cpp:182
+            if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+            kap = kap + kappa_e(m, P, de, dg, omega);
+            if (m == 0) {
+                const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
+                store(i, j, v);
+                store(j, i, v);
+            } else if (m == 1) {
+                const cd v = P.dx * kap;
+                store(i, j + N, v);
+                store(j, i + N, -v);
+                store(i + N, j, -v);
+                store(j + N, i, v);
+            } else {
+                const cd v = P.dx * kap;
+                store(i + N, j + N, v);
+                store(j + N, i + N, v);
             }
         }
     }
@@ -354,7 +364,9 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
 
 static CacheGeom make_geom(const NodeCacheGeom& g) {
     CacheGeom c;
-    c.dfull = g.dfull, c.rsub = g.rsub, c.ddeep = g.ddeep;
+    c.dfull = g.dfull;
+    c.rsub[0] = g.rsub, c.ddeep[0] = g.ddeep;
+    c.rsub[1] = g.rsub2, c.ddeep[1] = g.ddeep2;
     return c;
 }
 
@@ -363,8 +375,10 @@ size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g) {
     return (size_t)nitems * (size_t)make_geom(g).ni() * gw * sizeof(NodeRec);
 }
 
+int node_cache_intervals(const NodeCacheGeom& g) { return make_geom(g).ni(); }
+
 hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, double omi, void* recs,
-                             hipStream_t stream) {
+                             double* scale, hipStream_t stream) {
     CacheArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -373,6 +387,7 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, do
     A.geom = make_geom(g);
     A.omi = omi;
     A.recs = (NodeRec*)recs;
+    A.scale = scale;
     dim3 grid(256 * 32), block(256);
     if (L.gk_points == 15)
         hipLaunchKernelGGL(k_node_cache<15>, grid, block, 0, stream, A);
@@ -382,8 +397,9 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, do
 }
 
 hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
-                                  unsigned long long* worklist, unsigned int* worklist_count,
-                                  const int* act_idx, int n_act, hipStream_t stream) {
+                                  const double* scale, unsigned long long* worklist,
+                                  unsigned int* worklist_count, const int* act_idx, int n_act,
+                                  hipStream_t stream) {
     AsmCachedArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -391,6 +407,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     A.npairs = L.npairs;
     A.geom = make_geom(g);
     for (int c = 0; c < 2; ++c) A.recs[c] = (const NodeRec*)recs[c];
+    A.scale = scale;
     A.worklist = worklist;
     A.worklist_count = worklist_count;
     A.act_idx = act_idx;
@@ -411,7 +428,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     if (gx < 1) gx = 1;
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)chunks), block(256);
-    const size_t lds = (size_t)3 * L.P.N * sizeof(double);
+    const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
     if (L.gk_points == 15)
         hipLaunchKernelGGL(k_assemble_cached<15>, grid, block, lds, stream, A);
     else

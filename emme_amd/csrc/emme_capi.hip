@@ -70,12 +70,13 @@ struct emme_ctx {
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
     // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
     int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
-    NodeCacheGeom cache_geom{0, 0, 0};
+    NodeCacheGeom cache_geom{0, 0, 0, 0, 0};
     void* d_recs[2] = {nullptr, nullptr};
+    double* d_scale = nullptr;  // half-widths of the cached intervals
     unsigned long long* d_worklist = nullptr;  // integrals deferred to the on-the-fly kernel
     unsigned int* d_worklist_count = nullptr;
     size_t worklist_cap = 0;
-    double cache_budget_gb = 64.0;  // both classes together
+    double cache_budget_gb = 120.0;  // both classes together (MI355X: 288 GB of HBM3E)
     int mat_cap = 0;  // matrices per set
     double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
     double* d_iterates = nullptr;
@@ -218,8 +219,10 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         // largest geometry within the budget: deep right-hand subtree first (that is where
         // damped omegas refine), then the depth of the full tree
         const double per_class = c->cache_budget_gb * 0.5 * (1 << 30);
-        static const NodeCacheGeom options[] = {{7, 5, 13}, {6, 5, 13}, {6, 5, 12}, {6, 5, 11},
-                                                {5, 4, 10}, {5, 4, 9},  {4, 4, 4},  {3, 3, 3}};
+        static const NodeCacheGeom options[] = {
+            {7, 5, 13, 9, 18}, {6, 5, 13, 9, 18}, {6, 5, 13, 10, 18}, {7, 5, 13, 0, 0}, {6, 5, 13, 0, 0},
+            {6, 5, 12, 0, 0},  {6, 5, 11, 0, 0},  {5, 4, 10, 0, 0},   {5, 4, 9, 0, 0},  {4, 4, 4, 0, 0},
+            {3, 3, 3, 0, 0}};
         bool found = false;
         for (const auto& g : options) {
             if ((double)node_cache_bytes(L.gk_points, nitems, g) <= per_class) {
@@ -242,9 +245,15 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         c->cache_depth = -2;  // fall back to the on-the-fly kernels for good
         return false;
     }
+    if (!c->d_scale &&
+        hipMalloc((void**)&c->d_scale, sizeof(double) * node_cache_intervals(c->cache_geom)) != hipSuccess) {
+        (void)hipGetLastError();
+        c->cache_depth = -2;
+        return false;
+    }
     ScopedSpan s(c, K_OTHER);
-    if (launch_node_cache(L, c->cache_geom, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->stream) !=
-        hipSuccess) {
+    if (launch_node_cache(L, c->cache_geom, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_scale,
+                          c->stream) != hipSuccess) {
         c->cache_depth = -2;
         return false;
     }
@@ -311,9 +320,19 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
         ScopedSpan s(c, K_ASM);
-        HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_worklist, c->d_worklist_count,
+        HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_scale, c->d_worklist, c->d_worklist_count,
                                        c->d_actidx, n_act, c->stream));
         HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, c->stream));
+        if (std::getenv("EMME_DEBUG")) {
+            unsigned int cnt = 0;
+            (void)hipMemcpy(&cnt, c->d_worklist_count, sizeof cnt, hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> wl(cnt < 8 ? cnt : 8);
+            if (!wl.empty()) (void)hipMemcpy(wl.data(), c->d_worklist, wl.size() * 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[emme] cached fill: %d items, %u integrals deferred (of %ld)", n_act, cnt,
+                    (long)c->npairs * c->nm * n_act);
+            for (auto e : wl) fprintf(stderr, " b%llu:i%llu", e >> 32, e & 0xffffffffull);
+            fprintf(stderr, "\n");
+        }
     } else if (n_act >= c->wl_min) {
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
@@ -432,6 +451,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_M), F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (int k = 0; k < 2; ++k) F(c->d_recs[k]);
+    F(c->d_scale);
     F(c->d_worklist), F(c->d_worklist_count);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);

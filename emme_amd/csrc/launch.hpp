@@ -33,14 +33,17 @@ hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n
 // HBM cache of the omega-independent node records (assemble_cached.hip): full bisection tree
 // to depth dfull + the subtree under the rightmost depth-rsub node down to depth ddeep
 struct NodeCacheGeom {
-    int dfull, rsub, ddeep;
+    int dfull, rsub, ddeep;  // full tree depth; first right-hand subtree (prefix length, depth)
+    int rsub2, ddeep2;       // optional second, narrower and deeper subtree (0,0 = none)
 };
 size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g);
+int node_cache_intervals(const NodeCacheGeom& g);
 hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, double omi, void* recs,
-                             hipStream_t stream);
+                             double* scale, hipStream_t stream);
 hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
-                                  unsigned long long* worklist, unsigned int* worklist_count,
-                                  const int* act_idx, int n_act, hipStream_t stream);
+                                  const double* scale, unsigned long long* worklist,
+                                  unsigned int* worklist_count, const int* act_idx, int n_act,
+                                  hipStream_t stream);
 // integrals deferred by the cached kernel, recomputed by the lanes-are-nodes kernel
 hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
                                 const unsigned int* count, hipStream_t stream);
