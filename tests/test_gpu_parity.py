@@ -270,3 +270,55 @@ def test_trace_solve_sizes_against_lapack(emme, n):
     for b in range(nb):
         want = np.trace(np.linalg.solve(A[b], B[b]))
         assert abs(tr[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, tr[b], want)
+
+
+# ---- every fill kernel, forced through the context's environment switches ------------------
+KERNEL_MODES = {
+    # HBM node cache + independent-lane kernel (default), uncached integrals via work list
+    "cached": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1"},
+    # cache too small for anything but the shallowest tree: most integrals are deferred
+    "cached-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1"},
+    # no cache: omega-lane kernel (node data shared on the fly inside a lane group)
+    "omega-lane": {"EMME_NODE_CACHE_GB": "0", "EMME_WL_MIN": "1"},
+    # no cache, lanes-are-nodes kernel only
+    "nodes": {"EMME_NODE_CACHE_GB": "0", "EMME_WL_MIN": "100000"},
+}
+
+
+@pytest.mark.parametrize("mode", list(KERNEL_MODES))
+def test_every_fill_kernel_matches_oracle(emme, oracle, mode, monkeypatch):
+    for k, v in KERNEL_MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    cases = [
+        (example_tokamak(npoints=40), [-0.8 + 0.25j, -0.6 - 0.21j, 0.5 + 0.1j, -0.142 - 1.469j, 0.153 - 0.316j]),
+        (example_stellarator(npoints=10), [-1.656 + 2.49j, -0.85 - 0.32j, 0.4 - 0.2j]),
+    ]
+    for d, ws in cases:
+        po = oracle.params(d)
+        with _ctx(emme, d) as ctx:
+            M, iv = ctx.assemble(ws, want_intervals=True)
+            M1, iv1 = ctx.assemble(ws[1:2], want_intervals=True)
+        assert np.abs(M1[0] - M[1]).max() <= 1e-13 * np.abs(M[1]).max() and iv1[0] == iv[1]
+        for k, w in enumerate(ws):
+            Mo, tot = oracle.assemble(po, complex(w))
+            assert iv[k] == tot, (mode, d["conf"], w)
+            # (-0.142-1.469j) is a strongly damped point a wandering Newton chain visits:
+            # entries are ~1e38 and each is the remainder of integrand values ~1e8 times
+            # larger, so BOTH implementations carry ~1e-8 relative rounding there; the tree
+            # (interval count) must still be identical
+            tol = 1e-6 if w == -0.142 - 1.469j else TOL_M
+            assert np.abs(M[k] - Mo).max() <= tol * np.abs(Mo).max(), (mode, d["conf"], w)
+
+
+@pytest.mark.parametrize("mode", ["cached", "omega-lane", "nodes"])
+def test_root_search_same_in_every_kernel_mode(emme, oracle, mode, monkeypatch):
+    for k, v in KERNEL_MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    d = example_tokamak(npoints=32)
+    po = oracle.params(d)
+    guesses = np.array([-0.8 + 0.25j, -0.7 + 0.3j, -0.9 + 0.2j, -0.5 + 0.1j, 0.6 + 0.2j])
+    with _ctx(emme, d) as ctx:
+        roots, iters, info = ctx.solve_roots(guesses)
+    for b in (0, 3):
+        r_or, its_or, _, _ = oracle.solve_root(po, complex(guesses[b]))
+        assert iters[b] == len(its_or) and abs(roots[b] - r_or) <= TOL_W
