@@ -60,6 +60,7 @@ class Profile(C.Structure):
 
     _fields_ = [
         ("assemble_ms", C.c_double), ("assemble_launches", C.c_long),
+        ("deferred_ms", C.c_double), ("deferred_launches", C.c_long),
         ("linstep_ms", C.c_double), ("linstep_launches", C.c_long),
         ("other_ms", C.c_double), ("other_launches", C.c_long),
         ("gk_intervals", C.c_longlong), ("integrand_evals", C.c_longlong),
@@ -90,6 +91,9 @@ def load():
     lib.emme_ctx_destroy.restype = None
     lib.emme_ctx_set_stream.argtypes = [P, P]
     lib.emme_ctx_dim.argtypes = [P]
+    lib.emme_ctx_fill_mode.argtypes = [P]
+    lib.emme_ctx_node_cache_gib.argtypes = [P]
+    lib.emme_ctx_node_cache_gib.restype = C.c_double
     lib.emme_ctx_profile_enable.argtypes = [P, C.c_int]
     lib.emme_ctx_profile_read.argtypes = [P, C.POINTER(Profile), C.c_int]
     lib.emme_assemble_batch.argtypes = [P, P, C.c_int, P, P]
@@ -195,6 +199,15 @@ class Context:
 
     def set_stream(self, stream_handle: int):
         _check(self.lib.emme_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    FILL_KERNELS = {0: "k_assemble (lanes=nodes)", 1: "k_assemble_wl (omega-lane)",
+                    2: "k_assemble_cached (HBM node cache)"}
+
+    def fill_kernel(self) -> str:
+        return self.FILL_KERNELS.get(self.lib.emme_ctx_fill_mode(self.h), "none yet")
+
+    def node_cache_gib(self) -> float:
+        return self.lib.emme_ctx_node_cache_gib(self.h)
 
     def profile(self, on=True):
         _check(self.lib.emme_ctx_profile_enable(self.h, int(on)))

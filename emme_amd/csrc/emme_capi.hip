@@ -44,7 +44,7 @@ bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice;
 }
 
-enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2 };
+enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2, K_DEFER = 3 };
 
 }  // namespace
 }  // namespace emme
@@ -67,6 +67,7 @@ struct emme_ctx {
     unsigned long long* d_rounds = nullptr;  // diagnostic counter of the omega-lane kernel
     int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
+    int last_fill_mode = -1;   // kernel family of the last fill: 0 nodes, 1 omega-lane, 2 cached
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
     // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
     int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
@@ -136,6 +137,8 @@ int drain_spans(emme_ctx* c) {
             c->acc.assemble_ms += ms, c->acc.assemble_launches++;
         else if (s.kind == K_LIN)
             c->acc.linstep_ms += ms, c->acc.linstep_launches++;
+        else if (s.kind == K_DEFER)
+            c->acc.deferred_ms += ms, c->acc.deferred_launches++;
         else
             c->acc.other_ms += ms, c->acc.other_launches++;
         c->free_events.push_back(s.a);
@@ -319,10 +322,16 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
         HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
-        ScopedSpan s(c, K_ASM);
-        HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_scale, c->d_worklist, c->d_worklist_count,
-                                       c->d_actidx, n_act, c->stream));
-        HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, c->stream));
+        c->last_fill_mode = 2;
+        {
+            ScopedSpan s(c, K_ASM);
+            HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_scale, c->d_worklist,
+                                           c->d_worklist_count, c->d_actidx, n_act, c->stream));
+        }
+        {
+            ScopedSpan s(c, K_DEFER);
+            HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, c->stream));
+        }
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
             (void)hipMemcpy(&cnt, c->d_worklist_count, sizeof cnt, hipMemcpyDeviceToHost);
@@ -337,10 +346,12 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
         HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
+        c->last_fill_mode = 1;
         ScopedSpan s(c, K_ASM);
         HIP_TRY(launch_assemble_wl(L, c->d_actidx, n_act, c->stream));
     } else {
         L.items_per_group = items_per_group_for(c, nbatch);
+        c->last_fill_mode = 0;
         ScopedSpan s(c, K_ASM);
         HIP_TRY(launch_assemble(L, c->stream));
     }
@@ -465,6 +476,17 @@ int emme_ctx_set_stream(emme_ctx_t* c, void* s) {
 }
 
 int emme_ctx_dim(const emme_ctx_t* c) { return c ? c->dim : EMME_EINVAL; }
+
+int emme_ctx_fill_mode(const emme_ctx_t* c) { return c ? c->last_fill_mode : EMME_EINVAL; }
+
+double emme_ctx_node_cache_gib(const emme_ctx_t* c) {
+    if (!c || c->cache_depth < 0) return 0.0;
+    double b = 0.0;
+    for (int k = 0; k < 2; ++k)
+        if (c->d_recs[k])
+            b += (double)node_cache_bytes(c->p.integration_start_points, (long)c->npairs * c->nm, c->cache_geom);
+    return b / (1024.0 * 1024.0 * 1024.0);
+}
 
 int emme_ctx_profile_enable(emme_ctx_t* c, int on) {
     if (!c) return EMME_EINVAL;

@@ -46,8 +46,11 @@ typedef struct emme_ctx emme_ctx_t;
 /* Per-kernel device timing, filled when profiling is enabled (hipEvents recorded on the
  * context's stream around every launch). */
 typedef struct emme_profile {
-    double assemble_ms;       /* total time in the assembly kernel                  */
+    double assemble_ms;       /* total time in the main fill kernel (cached / omega-lane /
+                                 lanes-are-nodes, whichever the context dispatches)     */
     long assemble_launches;
+    double deferred_ms;       /* fill of integrals the cached kernel deferred (work list) */
+    long deferred_launches;
     double linstep_ms;        /* total time in the LU + trace kernel                */
     long linstep_launches;
     double other_ms;          /* copies / elementwise kernels                       */
@@ -82,6 +85,10 @@ void emme_ctx_destroy(emme_ctx_t* ctx);
 /* Launch everything on this hipStream_t (e.g. torch's current stream). NULL = default. */
 int emme_ctx_set_stream(emme_ctx_t* ctx, void* hip_stream);
 int emme_ctx_dim(const emme_ctx_t* ctx); /* N if beta_e == 0 else 2N */
+/* Kernel family used by the last fill: 0 lanes-are-nodes, 1 omega-lane, 2 HBM node cache. */
+int emme_ctx_fill_mode(const emme_ctx_t* ctx);
+/* GiB of HBM currently held by the node-record cache (0 if none). */
+double emme_ctx_node_cache_gib(const emme_ctx_t* ctx);
 int emme_ctx_profile_enable(emme_ctx_t* ctx, int on);
 int emme_ctx_profile_read(emme_ctx_t* ctx, emme_profile_t* out, int reset);
 
