@@ -27,50 +27,57 @@ namespace emme {
 
 namespace {
 
-struct NodeRec {  // one 64-byte line per (item, interval, node)
-    double2 A0, T, Q1, Q0;
+struct NodeRec {  // 48 bytes per (item, interval, node); T = i t~ does not depend on the pair
+    double2 A0, Q1, Q0;  // and lives in a small table shared by all items (L2-resident)
 };
 
-// Which intervals are cached.  Adaptive trees of this integrand are shallow everywhere except
-// towards t -> infinity (x -> pi/2), where damped omegas force a narrow, deep refinement; so
-// the cache holds the FULL tree down to depth `dfull` plus up to two full SUBTREES below
-// rightmost nodes (path prefix 11..1 of length rsub[k]) down to depth ddeep[k]: a wide one
-// for ordinary damped roots and a narrow, deeper one for strongly damped omegas.
+// Which intervals are cached.  Adaptive trees of this integrand are shallow almost everywhere;
+// damped omegas force narrow, deep refinements, mostly towards t -> infinity (x -> pi/2).  The
+// cache therefore holds the FULL tree down to depth `dfull` plus a list of full SUBTREES, each
+// given by its root (depth rd, path rp) and the depth dd it reaches.  Subtree 0 is fixed (under
+// the rightmost depth-5 node) and lives with the full tree in the main buffer; further
+// subtrees are added by the host at run time around intervals that integrals were found to
+// need (see emme_capi.hip), each in a buffer of its own.
 struct CacheGeom {
-    int dfull;            // full tree down to this depth
-    int rsub[2], ddeep[2];  // subtree under the rightmost depth-rsub node down to depth ddeep
+    int dfull;
+    int nsub;
+    int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB], base[NODE_CACHE_MAX_SUB];
+    unsigned long long rp[NODE_CACHE_MAX_SUB];
     __host__ __device__ int ni_full() const { return (2 << dfull) - 1; }
-    __host__ __device__ int ni_sub(int k) const {
-        return ddeep[k] > rsub[k] ? (2 << (ddeep[k] - rsub[k])) - 1 : 0;
-    }
-    __host__ __device__ int ni() const { return ni_full() + ni_sub(0) + ni_sub(1); }
-    // record slot of interval (depth, path), or -1 if it is not cached
-    __device__ int slot(int depth, unsigned long long path) const {
+    __host__ __device__ int ni_sub(int k) const { return (2 << (dd[k] - rd[k])) - 1; }
+    __host__ __device__ int ni_main() const { return ni_full() + (nsub > 0 ? ni_sub(0) : 0); }
+    __host__ __device__ int ni() const { return nsub > 0 ? base[nsub - 1] + ni_sub(nsub - 1) : ni_full(); }
+    // record slot of interval (depth, path), or -1 if it is not cached; *which = -1 for the
+    // main buffer, k-1 for the extension buffer of subtree k >= 1
+    __device__ int slot(int depth, unsigned long long path, int& which) const {
+        which = -1;
         if (depth <= dfull) return (1 << depth) - 1 + (int)path;
-        int base = ni_full();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (depth <= ddeep[k] && depth >= rsub[k]) {
-                const int sd = depth - rsub[k];
-                if ((path >> sd) == (1ull << rsub[k]) - 1ull)
-                    return base + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
+        for (int k = 0; k < nsub; ++k) {
+            if (depth <= dd[k] && depth >= rd[k]) {
+                const int sd = depth - rd[k];
+                if ((path >> sd) == rp[k]) {
+                    which = k - 1;
+                    return base[k] + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
+                }
             }
-            base += ni_sub(k);
         }
         return -1;
     }
-    // inverse of slot()
-    __device__ void interval(int idx, int& depth, unsigned long long& path) const {
-        if (idx < ni_full()) {
-            depth = 31 - __clz(idx + 1);
-            path = (unsigned long long)(idx + 1) - (1ull << depth);
-            return;
+    // inverse of slot() for the builder: part -1 = main buffer, part k >= 0 = subtree k+1
+    __device__ void interval(int part, int rel, int& depth, unsigned long long& path) const {
+        int k = part + 1;
+        if (part < 0) {
+            if (rel < ni_full()) {
+                depth = 31 - __clz(rel + 1);
+                path = (unsigned long long)(rel + 1) - (1ull << depth);
+                return;
+            }
+            rel -= ni_full();
+            k = 0;
         }
-        int k = 0, rel = idx - ni_full();
-        if (rel >= ni_sub(0)) rel -= ni_sub(0), k = 1;
         const int sd = 31 - __clz(rel + 1);
-        depth = rsub[k] + sd;
-        path = (((1ull << rsub[k]) - 1ull) << sd) | ((unsigned long long)(rel + 1) - (1ull << sd));
+        depth = rd[k] + sd;
+        path = (rp[k] << sd) | ((unsigned long long)(rel + 1) - (1ull << sd));
     }
 };
 
@@ -95,8 +102,11 @@ struct CacheArgs {
     int npairs;
     CacheGeom geom;
     double omi;      // class being built
-    NodeRec* recs;   // [nitems][NI][GW]
+    NodeRec* recs;   // [nitems][count][GW]: the cached intervals first .. first+count-1
+    double2* ttab;   // [NI][GW]  T per (interval, node), all regions
     double* scale;   // [NI] half-width (r - l)/2 of every cached interval
+    int part;          // -1: main buffer (full tree + subtree 0); k >= 0: subtree k+1
+    int first, count;  // global slot of the first interval and number of intervals filled
 };
 
 template <int PTS>
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     const DevParams& P = A.P;
     const int N = P.N;
-    const int NI = A.geom.ni();  // cached intervals per item
+    const int NI = A.count;  // intervals per item filled by this launch
     const int lane = threadIdx.x % GW;
     const long nitems = (long)A.npairs * P.nm;
     const long total = nitems * NI;
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
         const PairConst pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], gtab[i] - gtab[j]);
         int depth;
         unsigned long long path;
-        A.geom.interval(idx, depth, path);
+        A.geom.interval(A.part, idx, depth, path);
         double l, r;
         interval_bounds(depth, path, l, r);
         const double mid = (r + l) / 2, scale = (r - l) / 2;
@@ -132,11 +142,13 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
         const NodeData d = node_data(x, P, pc, A.omi, m);
         NodeRec rec;
         rec.A0 = make_double2(d.A0.x, d.A0.y);
-        rec.T = make_double2(d.T.x, d.T.y);
         rec.Q1 = make_double2(d.Q1.x, d.Q1.y);
         rec.Q0 = make_double2(d.Q0.x, d.Q0.y);
         A.recs[w * GW + lane] = rec;
-        if (item == 0 && lane == 0) A.scale[idx] = scale;
+        if (item == 0) {
+            A.ttab[(long)(A.first + idx) * GW + lane] = make_double2(d.T.x, d.T.y);
+            if (lane == 0) A.scale[A.first + idx] = scale;
+        }
     }
 }
 
@@ -146,9 +158,12 @@ struct AsmCachedArgs {
     const ushort2* pairs;
     int npairs;
     CacheGeom geom;
-    const NodeRec* recs[2];   // per contour class (omi = +1, -1); null if not built
+    const NodeRec* recs[2];   // main part per contour class (omi = +1, -1); null if not built
+    const NodeRec* recs_ext[2][NODE_CACHE_MAX_SUB - 1];  // run-time subtrees; null if absent
+    const double2* ttab[2];   // [NI][GW] per class
     const double* scale;      // [NI]
     unsigned long long* worklist;   // deferred integrals: batch << 32 | item
+    unsigned long long* defer_info; // depth << 56 | path of the interval each entry was missing
     unsigned int* worklist_count;
     const int* act_idx;
     int n_act;
@@ -197,7 +212,10 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
         omega = mk(A.omega[b].x, A.omega[b].y);
         if (A.Mold) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
     }
-    const NodeRec* recs = A.recs[-copysign(1.0, omega.x) > 0.0 ? 0 : 1];
+    const int cls = -copysign(1.0, omega.x) > 0.0 ? 0 : 1;
+    const NodeRec* recs = A.recs[cls];
+    const double2* ttab = A.ttab[cls];
+    const int NI_MAIN = A.geom.ni_main();
     double2* Mb = A.M + (size_t)b * dim * dim;
     const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
     double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
@@ -253,14 +271,18 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
         cd sum = mk(0.0, 0.0);
         int item_intervals = 0;
         bool walking = mine, deferred = false;
-        const NodeRec* ibase = recs + (long)item * NI * GW;
 
         while (walking) {
-            const int cslot = A.geom.slot(depth, path);
-            if (cslot < 0) {
+            int which;
+            const int cslot = A.geom.slot(depth, path, which);
+            const NodeRec* ebuf = which >= 0 ? A.recs_ext[cls][which] : recs;
+            if (cslot < 0 || ebuf == nullptr) {
                 // outside the cache: hand the whole integral to the on-the-fly kernel
                 const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+                // bits 58..63: depth, bits 17..57: low path bits (diagnostics only; the list
+                // kernel masks them off), bits 32..47 would collide with b, so b sits at 17+24
                 A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
+                A.defer_info[slot] = ((unsigned long long)depth << 56) | (path & 0xffffffffffffffull);
                 deferred = true;
                 walking = false;
                 continue;
@@ -268,14 +290,17 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
             const double scale = scale_tab[cslot];
             // ---- 15 (31) records of my interval, reference summation order -------------
             // (include/functions.h:186-201: centre, then f(+x_q) + f(-x_q) for q = 1..H-1)
-            const NodeRec* rp = ibase + (long)cslot * GW;
+            const NodeRec* rp =
+                which < 0 ? recs + ((long)item * NI_MAIN + cslot) * GW
+                          : ebuf + ((long)item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW;
+            const double2* tp = ttab + (long)cslot * GW;
             cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
             // visiting order s = 0..PTS-1: centre, +x_1, -x_1, +x_2, -x_2, ...
             auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
-            auto proc = [&](const NodeRec& rec, int s) {
+            auto proc = [&](const NodeRec& rec, const double2 tt, int s) {
                 NodeData d;
                 d.A0 = mk(rec.A0.x, rec.A0.y);
-                d.T = mk(rec.T.x, rec.T.y);
+                d.T = mk(tt.x, tt.y);
                 d.Q1 = mk(rec.Q1.x, rec.Q1.y);
                 d.Q0 = mk(rec.Q0.x, rec.Q0.y);
                 const cd f = node_eval(d, omega);
@@ -288,17 +313,18 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
                     if ((q & 1) == 0) G = G + WG[q >> 1] * fs;
                 }
             };
-            // three record buffers rotate so that two 64-byte loads are always in flight
-            // while a third record is being evaluated (each record is one cache line)
+            // three record buffers rotate so that two record loads are always in flight
+            // while a third record is being evaluated
             NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
+            double2 t0 = tp[node_of(0)], t1 = tp[node_of(1)], t2;
 #pragma unroll 1
             for (int s = 0; s < PTS; s += 3) {
-                if (s + 2 < PTS) r2 = rp[node_of(s + 2)];
-                proc(r0, s);
-                if (s + 3 < PTS) r0 = rp[node_of(s + 3)];
-                if (s + 1 < PTS) proc(r1, s + 1);
-                if (s + 4 < PTS) r1 = rp[node_of(s + 4)];
-                if (s + 2 < PTS) proc(r2, s + 2);
+                if (s + 2 < PTS) r2 = rp[node_of(s + 2)], t2 = tp[node_of(s + 2)];
+                proc(r0, t0, s);
+                if (s + 3 < PTS) r0 = rp[node_of(s + 3)], t0 = tp[node_of(s + 3)];
+                if (s + 1 < PTS) proc(r1, t1, s + 1);
+                if (s + 4 < PTS) r1 = rp[node_of(s + 4)], t1 = tp[node_of(s + 4)];
+                if (s + 2 < PTS) proc(r2, t2, s + 2);
             }
             ++item_intervals;
             // include/functions.h:203-208, 231-247
@@ -365,20 +391,32 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
 static CacheGeom make_geom(const NodeCacheGeom& g) {
     CacheGeom c;
     c.dfull = g.dfull;
-    c.rsub[0] = g.rsub, c.ddeep[0] = g.ddeep;
-    c.rsub[1] = g.rsub2, c.ddeep[1] = g.ddeep2;
+    c.nsub = g.nsub;
+    int base = c.ni_full();
+    for (int k = 0; k < NODE_CACHE_MAX_SUB; ++k) {
+        c.rd[k] = k < g.nsub ? g.rd[k] : 0;
+        c.dd[k] = k < g.nsub ? g.dd[k] : 0;
+        c.rp[k] = k < g.nsub ? g.rp[k] : 0;
+        c.base[k] = base;
+        if (k < g.nsub) base += c.ni_sub(k);
+    }
     return c;
 }
 
-size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g) {
+// part -1 = main buffer (full tree + subtree 0), part k >= 0 = run-time subtree k+1
+size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g, int part) {
     const int gw = gk_points == 15 ? 16 : 32;
-    return (size_t)nitems * (size_t)make_geom(g).ni() * gw * sizeof(NodeRec);
+    const CacheGeom c = make_geom(g);
+    const int ni = part < 0 ? c.ni_main() : c.ni_sub(part + 1);
+    return (size_t)nitems * (size_t)ni * gw * sizeof(NodeRec);
+}
+int node_cache_intervals(const NodeCacheGeom& g) { return make_geom(g).ni(); }
+size_t node_ttab_bytes(int gk_points, int max_intervals) {
+    return (size_t)max_intervals * (gk_points == 15 ? 16 : 32) * sizeof(double2);
 }
 
-int node_cache_intervals(const NodeCacheGeom& g) { return make_geom(g).ni(); }
-
-hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, double omi, void* recs,
-                             double* scale, hipStream_t stream) {
+hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
+                             void* recs, void* ttab, double* scale, hipStream_t stream) {
     CacheArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -387,7 +425,12 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, do
     A.geom = make_geom(g);
     A.omi = omi;
     A.recs = (NodeRec*)recs;
+    A.ttab = (double2*)ttab;
     A.scale = scale;
+    A.part = part;
+    A.first = part < 0 ? 0 : A.geom.base[part + 1];
+    A.count = part < 0 ? A.geom.ni_main() : A.geom.ni_sub(part + 1);
+    if (A.count == 0) return hipSuccess;
     dim3 grid(256 * 32), block(256);
     if (L.gk_points == 15)
         hipLaunchKernelGGL(k_node_cache<15>, grid, block, 0, stream, A);
@@ -396,9 +439,12 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, do
     return hipGetLastError();
 }
 
-hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
-                                  const double* scale, unsigned long long* worklist,
-                                  unsigned int* worklist_count, const int* act_idx, int n_act,
+hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g,
+                                  const void* const recs[2],
+                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                                  const void* const ttab[2], const double* scale,
+                                  unsigned long long* worklist, unsigned int* worklist_count,
+                                  unsigned long long* defer_info, const int* act_idx, int n_act,
                                   hipStream_t stream) {
     AsmCachedArgs A;
     A.P = L.P;
@@ -406,10 +452,15 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     A.pairs = (const ushort2*)L.pairs;
     A.npairs = L.npairs;
     A.geom = make_geom(g);
-    for (int c = 0; c < 2; ++c) A.recs[c] = (const NodeRec*)recs[c];
+    for (int c = 0; c < 2; ++c) {
+        A.recs[c] = (const NodeRec*)recs[c];
+        for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k) A.recs_ext[c][k] = (const NodeRec*)recs_ext[c][k];
+        A.ttab[c] = (const double2*)ttab[c];
+    }
     A.scale = scale;
     A.worklist = worklist;
     A.worklist_count = worklist_count;
+    A.defer_info = defer_info;
     A.act_idx = act_idx;
     A.n_act = n_act;
     A.omega = (const double2*)L.omega;

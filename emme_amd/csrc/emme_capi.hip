@@ -71,8 +71,15 @@ struct emme_ctx {
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
     // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
     int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
-    NodeCacheGeom cache_geom{0, 0, 0, 0, 0};
-    void* d_recs[2] = {nullptr, nullptr};
+    NodeCacheGeom cache_geom{};
+    int cache_max_intervals = 0;  // capacity of the T / scale tables
+    void* d_recs[2] = {nullptr, nullptr};      // main part per contour class
+    void* d_recs_ext[2][NODE_CACHE_MAX_SUB - 1] = {};  // run-time subtrees per class
+    void* d_ttab[2] = {nullptr, nullptr};      // T table per class
+    bool ext_failed = false;
+    unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
+    double cache_bytes_used = 0.0;
+    unsigned int last_deferred = 0;            // integrals the previous cached fill deferred
     double* d_scale = nullptr;  // half-widths of the cached intervals
     unsigned long long* d_worklist = nullptr;  // integrals deferred to the on-the-fly kernel
     unsigned int* d_worklist_count = nullptr;
@@ -213,22 +220,22 @@ int items_per_group_for(const emme_ctx* c, long units) {
     return (int)ipg;
 }
 
-// Make sure the node cache of contour class `cls` (0: omi=+1, 1: omi=-1) exists.
-// Returns false (and disables the cache) if it cannot be allocated within the budget.
+// Make sure the main part of the node cache of contour class `cls` (0: omi=+1, 1: omi=-1)
+// exists.  Returns false (and disables the cache) if it does not fit the budget.
 bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->cache_depth == -2) return false;
     const long nitems = (long)c->npairs * c->nm;
+    const double budget = c->cache_budget_gb * (double)(1 << 30);
     if (c->cache_depth == -1) {
-        // largest geometry within the budget: deep right-hand subtree first (that is where
-        // damped omegas refine), then the depth of the full tree
-        const double per_class = c->cache_budget_gb * 0.5 * (1 << 30);
-        static const NodeCacheGeom options[] = {
-            {7, 5, 13, 9, 18}, {6, 5, 13, 9, 18}, {6, 5, 13, 10, 18}, {7, 5, 13, 0, 0}, {6, 5, 13, 0, 0},
-            {6, 5, 12, 0, 0},  {6, 5, 11, 0, 0},  {5, 4, 10, 0, 0},   {5, 4, 9, 0, 0},  {4, 4, 4, 0, 0},
-            {3, 3, 3, 0, 0}};
+        // full tree to depth dfull + the fixed subtree under the rightmost depth-5 node (that is
+        // where ordinary damped roots refine); the largest that leaves half the budget free
+        static const int options[][3] = {{8, 5, 13}, {7, 5, 13}, {6, 5, 13}, {6, 5, 12}, {6, 5, 11},
+                                         {5, 4, 10}, {5, 4, 9},  {4, 3, 7},  {3, 2, 5}};
         bool found = false;
-        for (const auto& g : options) {
-            if ((double)node_cache_bytes(L.gk_points, nitems, g) <= per_class) {
+        for (const auto& o : options) {
+            NodeCacheGeom g{};
+            g.dfull = o[0], g.nsub = 1, g.rd[0] = o[1], g.dd[0] = o[2], g.rp[0] = (1ull << o[1]) - 1ull;
+            if ((double)node_cache_bytes(L.gk_points, nitems, g, -1) <= 0.25 * budget) {
                 c->cache_geom = g;
                 found = true;
                 break;
@@ -239,28 +246,82 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
             return false;
         }
         c->cache_depth = c->cache_geom.dfull;
+        c->cache_max_intervals = node_cache_intervals(c->cache_geom) + (NODE_CACHE_MAX_SUB - 1) * 511;
     }
     if (c->d_recs[cls]) return true;
-    const size_t bytes = node_cache_bytes(L.gk_points, nitems, c->cache_geom);
-    if (hipMalloc(&c->d_recs[cls], bytes) != hipSuccess) {
+    const size_t bytes = node_cache_bytes(L.gk_points, nitems, c->cache_geom, -1);
+    if (c->cache_bytes_used + (double)bytes > budget ||
+        hipMalloc(&c->d_recs[cls], bytes) != hipSuccess ||
+        hipMalloc(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
+        (!c->d_scale &&
+         hipMalloc((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
         (void)hipGetLastError();
+        if (c->d_recs[cls]) (void)hipFree(c->d_recs[cls]);
         c->d_recs[cls] = nullptr;
         c->cache_depth = -2;  // fall back to the on-the-fly kernels for good
         return false;
     }
-    if (!c->d_scale &&
-        hipMalloc((void**)&c->d_scale, sizeof(double) * node_cache_intervals(c->cache_geom)) != hipSuccess) {
-        (void)hipGetLastError();
+    c->cache_bytes_used += (double)bytes;
+    ScopedSpan s(c, K_OTHER);
+    if (launch_node_cache(L, c->cache_geom, -1, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_ttab[cls],
+                          c->d_scale, c->stream) != hipSuccess) {
         c->cache_depth = -2;
         return false;
     }
-    ScopedSpan s(c, K_OTHER);
-    if (launch_node_cache(L, c->cache_geom, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_scale,
-                          c->stream) != hipSuccess) {
-        c->cache_depth = -2;
-        return false;
+    // run-time subtrees already registered (built for the other class): build them here too
+    for (int k = 1; k < c->cache_geom.nsub; ++k) {
+        const size_t eb = node_cache_bytes(L.gk_points, nitems, c->cache_geom, k - 1);
+        if (c->cache_bytes_used + (double)eb > budget) break;
+        if (hipMalloc(&c->d_recs_ext[cls][k - 1], eb) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_recs_ext[cls][k - 1] = nullptr;
+            break;
+        }
+        c->cache_bytes_used += (double)eb;
+        (void)launch_node_cache(L, c->cache_geom, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1],
+                                c->d_ttab[cls], c->d_scale, c->stream);
     }
     return true;
+}
+
+// The previous cached fill deferred integrals because interval (depth, path) was not cached:
+// register a new subtree around it (root 4 levels up, 8 levels deep = 511 intervals) and
+// build it for the contour classes in use.  Failure is harmless: those integrals keep going
+// through the work list.
+void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned long long path,
+                       const bool need[2]) {
+    NodeCacheGeom& g = c->cache_geom;
+    if (g.nsub >= NODE_CACHE_MAX_SUB || c->ext_failed) return;
+    const int rd = depth - 4 < 1 ? 1 : depth - 4;
+    const int k = g.nsub;
+    g.rd[k] = rd;
+    g.rp[k] = path >> (depth - rd);
+    g.dd[k] = rd + 8;
+    g.nsub = k + 1;
+    const long nitems = (long)c->npairs * c->nm;
+    const double budget = c->cache_budget_gb * (double)(1 << 30);
+    const size_t eb = node_cache_bytes(L.gk_points, nitems, g, k - 1);
+    bool any = false;
+    for (int cls = 0; cls < 2; ++cls) {
+        if (!need[cls] || !c->d_recs[cls]) continue;
+        if (c->cache_bytes_used + (double)eb > budget ||
+            hipMalloc(&c->d_recs_ext[cls][k - 1], eb) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_recs_ext[cls][k - 1] = nullptr;
+            c->ext_failed = true;
+            break;
+        }
+        c->cache_bytes_used += (double)eb;
+        ScopedSpan s(c, K_OTHER);
+        if (launch_node_cache(L, g, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1], c->d_ttab[cls],
+                              c->d_scale, c->stream) != hipSuccess)
+            c->ext_failed = true;
+        any = true;
+    }
+    if (!any) g.nsub = k;  // nothing built: forget the registration
+    if (std::getenv("EMME_DEBUG"))
+        fprintf(stderr, "[emme] node cache: subtree %d added at depth %d path %llx (to depth %d), %.1f GiB in use\n",
+                k, rd, g.rp[k], g.dd[k], c->cache_bytes_used / (double)(1 << 30));
 }
 
 // host_active: which of the nbatch items to assemble (null = all).  Batches of wl_min or
@@ -305,6 +366,28 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         for (int b : idx) need[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1] = true;
         for (int k = 0; k < 2 && use_cache; ++k)
             if (need[k]) use_cache = ensure_node_cache(c, L, k);
+        // the previous cached fill deferred a sizeable share of its integrals: look at which
+        // intervals they were missing and cache a subtree around the most frequent one(s)
+        if (use_cache && c->d_worklist_count && c->d_defer_info) {
+            HIP_TRY(hipMemcpyAsync(&c->last_deferred, c->d_worklist_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if ((long)c->last_deferred * 8 >= (long)c->npairs * c->nm && c->cache_geom.nsub < NODE_CACHE_MAX_SUB) {
+                const size_t cnt = std::min<size_t>(c->last_deferred, 1u << 16);
+                std::vector<unsigned long long> info(cnt);
+                HIP_TRY(hipMemcpy(info.data(), c->d_defer_info, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                std::sort(info.begin(), info.end());
+                unsigned long long best = 0;
+                size_t best_n = 0;
+                for (size_t q = 0; q < cnt;) {
+                    size_t e = q;
+                    while (e < cnt && info[e] == info[q]) ++e;
+                    if (e - q > best_n) best_n = e - q, best = info[q];
+                    q = e;
+                }
+                if (best_n * 4 >= cnt)
+                    add_cache_subtree(c, L, (int)(best >> 56), best & 0xffffffffffffffull, need);
+            }
+        }
     }
     if (use_cache) {
         // work list for integrals that outgrow the cache (worst case: every one of them)
@@ -313,9 +396,13 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             if (c->d_worklist) (void)hipFree(c->d_worklist);
             c->d_worklist = nullptr;
             HIP_TRY(hipMalloc((void**)&c->d_worklist, need * sizeof(unsigned long long)));
+            if (c->d_defer_info) (void)hipFree(c->d_defer_info);
+            c->d_defer_info = nullptr;
+            HIP_TRY(hipMalloc((void**)&c->d_defer_info, need * sizeof(unsigned long long)));
             c->worklist_cap = need;
         }
         if (!c->d_worklist_count) HIP_TRY(hipMalloc((void**)&c->d_worklist_count, sizeof(unsigned int)));
+
     }
     if (use_cache) {
         const int gw = L.gk_points == 15 ? 16 : 32;
@@ -325,8 +412,9 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         c->last_fill_mode = 2;
         {
             ScopedSpan s(c, K_ASM);
-            HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_scale, c->d_worklist,
-                                           c->d_worklist_count, c->d_actidx, n_act, c->stream));
+            HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale,
+                                           c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx,
+                                           n_act, c->stream));
         }
         {
             ScopedSpan s(c, K_DEFER);
@@ -339,7 +427,11 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             if (!wl.empty()) (void)hipMemcpy(wl.data(), c->d_worklist, wl.size() * 8, hipMemcpyDeviceToHost);
             fprintf(stderr, "[emme] cached fill: %d items, %u integrals deferred (of %ld)", n_act, cnt,
                     (long)c->npairs * c->nm * n_act);
-            for (auto e : wl) fprintf(stderr, " b%llu:i%llu", e >> 32, e & 0xffffffffull);
+            std::vector<unsigned long long> dg(wl.size());
+            if (!wl.empty() && c->d_defer_info) (void)hipMemcpy(dg.data(), c->d_defer_info, wl.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t q = 0; q < wl.size(); ++q)
+                fprintf(stderr, " b%llu:i%llu@d%llu:p%llx", wl[q] >> 32, wl[q] & 0xffffffffull, dg[q] >> 56,
+                        dg[q] & 0xffffffffffffffull);
             fprintf(stderr, "\n");
         }
     } else if (n_act >= c->wl_min) {
@@ -461,9 +553,12 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
         F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_M), F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
-    for (int k = 0; k < 2; ++k) F(c->d_recs[k]);
+    for (int k = 0; k < 2; ++k) {
+        F(c->d_recs[k]), F(c->d_ttab[k]);
+        for (int e = 0; e < NODE_CACHE_MAX_SUB - 1; ++e) F(c->d_recs_ext[k][e]);
+    }
     F(c->d_scale);
-    F(c->d_worklist), F(c->d_worklist_count);
+    F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     delete c;
@@ -480,12 +575,7 @@ int emme_ctx_dim(const emme_ctx_t* c) { return c ? c->dim : EMME_EINVAL; }
 int emme_ctx_fill_mode(const emme_ctx_t* c) { return c ? c->last_fill_mode : EMME_EINVAL; }
 
 double emme_ctx_node_cache_gib(const emme_ctx_t* c) {
-    if (!c || c->cache_depth < 0) return 0.0;
-    double b = 0.0;
-    for (int k = 0; k < 2; ++k)
-        if (c->d_recs[k])
-            b += (double)node_cache_bytes(c->p.integration_start_points, (long)c->npairs * c->nm, c->cache_geom);
-    return b / (1024.0 * 1024.0 * 1024.0);
+    return c ? c->cache_bytes_used / (1024.0 * 1024.0 * 1024.0) : 0.0;
 }
 
 int emme_ctx_profile_enable(emme_ctx_t* c, int on) {

@@ -30,19 +30,29 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream);
 hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n_act,
                               hipStream_t stream);
 
-// HBM cache of the omega-independent node records (assemble_cached.hip): full bisection tree
-// to depth dfull + the subtree under the rightmost depth-rsub node down to depth ddeep
+// HBM cache of the omega-independent node records (assemble_cached.hip): the full bisection
+// tree down to depth dfull plus up to NODE_CACHE_MAX_SUB full subtrees (root depth rd, root
+// path rp, down to depth dd).  Subtree 0 shares the main buffer with the full tree; the others
+// are added at run time, each in its own buffer.
+constexpr int NODE_CACHE_MAX_SUB = 6;
 struct NodeCacheGeom {
-    int dfull, rsub, ddeep;  // full tree depth; first right-hand subtree (prefix length, depth)
-    int rsub2, ddeep2;       // optional second, narrower and deeper subtree (0,0 = none)
+    int dfull;
+    int nsub;
+    int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB];
+    unsigned long long rp[NODE_CACHE_MAX_SUB];
 };
-size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g);
+// part -1 = main buffer (full tree + subtree 0), part k >= 0 = run-time subtree k+1
+size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g, int part);
+size_t node_ttab_bytes(int gk_points, int max_intervals);
 int node_cache_intervals(const NodeCacheGeom& g);
-hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, double omi, void* recs,
-                             double* scale, hipStream_t stream);
-hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
-                                  const double* scale, unsigned long long* worklist,
-                                  unsigned int* worklist_count, const int* act_idx, int n_act,
+hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
+                             void* recs, void* ttab, double* scale, hipStream_t stream);
+hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g,
+                                  const void* const recs[2],
+                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                                  const void* const ttab[2], const double* scale,
+                                  unsigned long long* worklist, unsigned int* worklist_count,
+                                  unsigned long long* defer_info, const int* act_idx, int n_act,
                                   hipStream_t stream);
 // integrals deferred by the cached kernel, recomputed by the lanes-are-nodes kernel
 hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
