@@ -16,6 +16,7 @@
 
 #include "assemble_common.hpp"
 #include "launch.hpp"
+#include "node_cache.hpp"
 
 namespace emme {
 
@@ -37,6 +38,11 @@ struct AsmArgs {
     // LIST mode: explicit (batch index, item) entries instead of the (item, blockIdx.y) grid
     const unsigned long long* worklist;  // entry = batch << 32 | item
     const unsigned int* worklist_count;
+    // LIST mode: node-record cache, used for every interval it holds (null = none)
+    CacheGeom geom;
+    const NodeRec* recs[2];
+    const NodeRec* recs_ext[2][NODE_CACHE_MAX_SUB - 1];
+    const double2* ttab[2];
 };
 
 template <int PTS, bool LIST>
@@ -153,7 +159,36 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
         // abscissa scale * x + mid, rounded like the reference (no FMA contraction)
         const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
 
-        const cd f = integrand(x, P, pc, oc, m);
+        cd f;
+        const int cls = oc.omi > 0.0 ? 0 : 1;
+        if (LIST || A.recs[cls] != nullptr) {
+            // Node-record cache available: take the record (lane = node) wherever there is
+            // one and compute the node data on the spot only for uncached intervals.  Used
+            // for integrals the cached kernel deferred (LIST) and for omegas whose integrals
+            // are so long (hundreds of intervals) that their serial latency matters more than
+            // throughput: here all 15 (31) nodes of an interval advance in parallel.
+            int which;
+            const int cslot = A.recs[cls] ? A.geom.slot(depth, path, which) : -1;
+            const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? A.recs[cls] : A.recs_ext[cls][which]);
+            NodeData d;
+            if (buf) {
+                const long it = LIST ? (long)(A.worklist[item] & 0xffffffffull) : (long)item;
+                const NodeRec rec =
+                    which < 0 ? buf[(it * A.geom.ni_main() + cslot) * GW + lane_in_group]
+                              : buf[(it * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
+                                    lane_in_group];
+                const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
+                d.A0 = mk(rec.A0.x, rec.A0.y);
+                d.T = mk(tt.x, tt.y);
+                d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+                d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+            } else {
+                d = node_data(x, P, pc, oc.omi, m);
+            }
+            f = node_eval(d, oc.omega);
+        } else {
+            f = integrand(x, P, pc, oc, m);
+        }
         const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
         const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
         ++my_intervals;
@@ -239,7 +274,10 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
 
 }  // namespace
 
-hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream) {
+hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const NodeCacheGeom* g,
+                           const void* const recs[2],
+                           const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                           const void* const ttab[2]) {
     AsmArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -255,6 +293,13 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream) {
     A.status = L.status;
     A.worklist = nullptr;
     A.worklist_count = nullptr;
+    A.geom = g ? make_geom(*g) : CacheGeom{};
+    for (int c = 0; c < 2; ++c) {
+        A.recs[c] = g ? (const NodeRec*)recs[c] : nullptr;
+        A.ttab[c] = g ? (const double2*)ttab[c] : nullptr;
+        for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k)
+            A.recs_ext[c][k] = g ? (const NodeRec*)recs_ext[c][k] : nullptr;
+    }
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     const long nitems = (long)L.npairs * L.P.nm;
@@ -278,7 +323,10 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream) {
 // recomputed whole by the lanes-are-nodes kernel from a device-side list whose length the
 // host does not know -- a fixed grid strides over it and exits at once when it is empty.
 hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
-                                const unsigned int* count, hipStream_t stream) {
+                                const unsigned int* count, const NodeCacheGeom* g,
+                                const void* const recs[2],
+                                const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                                const void* const ttab[2], hipStream_t stream) {
     AsmArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -294,6 +342,13 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     A.status = L.status;
     A.worklist = worklist;
     A.worklist_count = count;
+    A.geom = g ? make_geom(*g) : CacheGeom{};
+    for (int c = 0; c < 2; ++c) {
+        A.recs[c] = g ? (const NodeRec*)recs[c] : nullptr;
+        A.ttab[c] = g ? (const double2*)ttab[c] : nullptr;
+        for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k)
+            A.recs_ext[c][k] = g ? (const NodeRec*)recs_ext[c][k] : nullptr;
+    }
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     dim3 grid(2048), block(256);

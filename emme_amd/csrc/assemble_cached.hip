@@ -22,64 +22,11 @@
 
 #include "assemble_common.hpp"
 #include "launch.hpp"
+#include "node_cache.hpp"
 
 namespace emme {
 
 namespace {
-
-struct NodeRec {  // 48 bytes per (item, interval, node); T = i t~ does not depend on the pair
-    double2 A0, Q1, Q0;  // and lives in a small table shared by all items (L2-resident)
-};
-
-// Which intervals are cached.  Adaptive trees of this integrand are shallow almost everywhere;
-// damped omegas force narrow, deep refinements, mostly towards t -> infinity (x -> pi/2).  The
-// cache therefore holds the FULL tree down to depth `dfull` plus a list of full SUBTREES, each
-// given by its root (depth rd, path rp) and the depth dd it reaches.  Subtree 0 is fixed (under
-// the rightmost depth-5 node) and lives with the full tree in the main buffer; further
-// subtrees are added by the host at run time around intervals that integrals were found to
-// need (see emme_capi.hip), each in a buffer of its own.
-struct CacheGeom {
-    int dfull;
-    int nsub;
-    int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB], base[NODE_CACHE_MAX_SUB];
-    unsigned long long rp[NODE_CACHE_MAX_SUB];
-    __host__ __device__ int ni_full() const { return (2 << dfull) - 1; }
-    __host__ __device__ int ni_sub(int k) const { return (2 << (dd[k] - rd[k])) - 1; }
-    __host__ __device__ int ni_main() const { return ni_full() + (nsub > 0 ? ni_sub(0) : 0); }
-    __host__ __device__ int ni() const { return nsub > 0 ? base[nsub - 1] + ni_sub(nsub - 1) : ni_full(); }
-    // record slot of interval (depth, path), or -1 if it is not cached; *which = -1 for the
-    // main buffer, k-1 for the extension buffer of subtree k >= 1
-    __device__ int slot(int depth, unsigned long long path, int& which) const {
-        which = -1;
-        if (depth <= dfull) return (1 << depth) - 1 + (int)path;
-        for (int k = 0; k < nsub; ++k) {
-            if (depth <= dd[k] && depth >= rd[k]) {
-                const int sd = depth - rd[k];
-                if ((path >> sd) == rp[k]) {
-                    which = k - 1;
-                    return base[k] + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
-                }
-            }
-        }
-        return -1;
-    }
-    // inverse of slot() for the builder: part -1 = main buffer, part k >= 0 = subtree k+1
-    __device__ void interval(int part, int rel, int& depth, unsigned long long& path) const {
-        int k = part + 1;
-        if (part < 0) {
-            if (rel < ni_full()) {
-                depth = 31 - __clz(rel + 1);
-                path = (unsigned long long)(rel + 1) - (1ull << depth);
-                return;
-            }
-            rel -= ni_full();
-            k = 0;
-        }
-        const int sd = 31 - __clz(rel + 1);
-        depth = rd[k] + sd;
-        path = (rp[k] << sd) | ((unsigned long long)(rel + 1) - (1ull << sd));
-    }
-};
 
 // [l, r] of interval (depth, path) with the reference's midpoint sequence
 __device__ __forceinline__ void interval_bounds(int depth, unsigned long long path, double& l,
@@ -165,7 +112,8 @@ struct AsmCachedArgs {
     unsigned long long* worklist;   // deferred integrals: batch << 32 | item
     unsigned long long* defer_info; // depth << 56 | path of the interval each entry was missing
     unsigned int* worklist_count;
-    const int* act_idx;
+    const int* act_idx;      // batch indices, chunk after chunk
+    const int2* chunks;      // per omega chunk (blockIdx.y): (first position in act_idx, size <= GW)
     int n_act;
     const double2* omega;
     double2* M;
@@ -200,13 +148,14 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
     // lane -> (omega slot, item stream).  A chunk holds up to GW omegas; when it holds fewer
     // (small batches, the tail of a root search) the spare lanes take further item streams of
     // the same omegas, so a single omega still fills all lanes.
-    const int n_in_chunk = min(GW, A.n_act - (int)blockIdx.y * GW);
+    const int2 chunk = A.chunks[blockIdx.y];
+    const int n_in_chunk = chunk.y;
     int n_eff = 1;
     while (n_eff < n_in_chunk) n_eff <<= 1;
     const int nsub = GW / n_eff;
     const int wslot = lane % n_eff, sub = lane / n_eff;
     const bool has_w = wslot < n_in_chunk;
-    const int b = has_w ? A.act_idx[blockIdx.y * GW + wslot] : 0;
+    const int b = has_w ? A.act_idx[chunk.x + wslot] : 0;
     cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
     if (has_w) {
         omega = mk(A.omega[b].x, A.omega[b].y);
@@ -388,21 +337,6 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
 
 }  // namespace
 
-static CacheGeom make_geom(const NodeCacheGeom& g) {
-    CacheGeom c;
-    c.dfull = g.dfull;
-    c.nsub = g.nsub;
-    int base = c.ni_full();
-    for (int k = 0; k < NODE_CACHE_MAX_SUB; ++k) {
-        c.rd[k] = k < g.nsub ? g.rd[k] : 0;
-        c.dd[k] = k < g.nsub ? g.dd[k] : 0;
-        c.rp[k] = k < g.nsub ? g.rp[k] : 0;
-        c.base[k] = base;
-        if (k < g.nsub) base += c.ni_sub(k);
-    }
-    return c;
-}
-
 // part -1 = main buffer (full tree + subtree 0), part k >= 0 = run-time subtree k+1
 size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g, int part) {
     const int gw = gk_points == 15 ? 16 : 32;
@@ -445,8 +379,9 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
                                   const void* const ttab[2], const double* scale,
                                   unsigned long long* worklist, unsigned int* worklist_count,
                                   unsigned long long* defer_info, const int* act_idx, int n_act,
-                                  hipStream_t stream) {
+                                  const void* chunks, int nchunks, hipStream_t stream) {
     AsmCachedArgs A;
+    A.chunks = (const int2*)chunks;
     A.P = L.P;
     A.tab = L.tab;
     A.pairs = (const ushort2*)L.pairs;
@@ -472,13 +407,12 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     A.status = L.status;
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
-    const int chunks = (n_act + gw - 1) / gw;
     const long nitems = (long)L.npairs * L.P.nm;
     long want_groups = (nitems + L.items_per_group - 1) / L.items_per_group;
     long gx = (want_groups + groups_per_block - 1) / groups_per_block;
     if (gx < 1) gx = 1;
     if (gx > 65535) gx = 65535;
-    dim3 grid((unsigned)gx, (unsigned)chunks), block(256);
+    dim3 grid((unsigned)gx, (unsigned)nchunks), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
     if (L.gk_points == 15)
         hipLaunchKernelGGL(k_assemble_cached<15>, grid, block, lds, stream, A);

@@ -66,6 +66,14 @@ struct emme_ctx {
     unsigned long long* d_intervals = nullptr;
     unsigned long long* d_rounds = nullptr;  // diagnostic counter of the omega-lane kernel
     int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
+    int* d_chunks = nullptr;   // (first, size) of every omega chunk of the cached kernel
+    int* d_longmask = nullptr; // batch items routed to the lanes-are-nodes kernel (long integrals)
+    std::vector<int> h_longmask;
+    hipStream_t stream2 = nullptr;  // the two fill kernels of one assembly run side by side
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    double long_threshold = 1e30;  // off by default (no gain measured on the bench workload)
+    // // mean GK intervals per integral above which an omega is "long"
+    std::vector<int> h_chunks;
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
     int last_fill_mode = -1;   // kernel family of the last fill: 0 nodes, 1 omega-lane, 2 cached
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
@@ -84,7 +92,7 @@ struct emme_ctx {
     unsigned long long* d_worklist = nullptr;  // integrals deferred to the on-the-fly kernel
     unsigned int* d_worklist_count = nullptr;
     size_t worklist_cap = 0;
-    double cache_budget_gb = 120.0;  // both classes together (MI355X: 288 GB of HBM3E)
+    double cache_budget_gb = 176.0;  // both classes together (MI355X: 288 GB of HBM3E)
     int mat_cap = 0;  // matrices per set
     double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
     double* d_iterates = nullptr;
@@ -119,17 +127,19 @@ hipEvent_t get_event(emme_ctx* c) {
 struct ScopedSpan {
     emme_ctx* c;
     int kind;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedSpan(emme_ctx* ctx, int k) : c(ctx), kind(k) {
+    ScopedSpan(emme_ctx* ctx, int k, hipStream_t on = nullptr, bool use_on = false)
+        : c(ctx), kind(k), st(use_on ? on : ctx->stream) {
         if (c->prof) {
             a = get_event(c);
             b = get_event(c);
-            if (a) (void)hipEventRecord(a, c->stream);
+            if (a) (void)hipEventRecord(a, st);
         }
     }
     ~ScopedSpan() {
         if (c->prof && a && b) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             c->spans.push_back({kind, a, b});
         }
     }
@@ -162,7 +172,7 @@ int ensure_batch(emme_ctx* c, int nb) {
         p = nullptr;
     };
     F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active), F(c->d_iters), F(c->d_info),
-        F(c->d_status), F(c->d_intervals), F(c->d_actidx);
+        F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks), F(c->d_longmask);
     c->cap = 0;
     HIP_TRY(hipMalloc((void**)&c->d_omega, sizeof(double) * 2 * nb));
     HIP_TRY(hipMalloc((void**)&c->d_domega, sizeof(double) * 2 * nb));
@@ -173,6 +183,8 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(int) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_actidx, sizeof(int) * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_chunks, sizeof(int) * 2 * nb));
+    HIP_TRY(hipMalloc((void**)&c->d_longmask, sizeof(int) * nb));
     if (!c->d_rounds) {
         HIP_TRY(hipMalloc((void**)&c->d_rounds, sizeof(unsigned long long)));
         HIP_TRY(hipMemset(c->d_rounds, 0, sizeof(unsigned long long)));
@@ -371,7 +383,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (use_cache && c->d_worklist_count && c->d_defer_info) {
             HIP_TRY(hipMemcpyAsync(&c->last_deferred, c->d_worklist_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if ((long)c->last_deferred * 8 >= (long)c->npairs * c->nm && c->cache_geom.nsub < NODE_CACHE_MAX_SUB) {
+            if (c->last_deferred >= 32 && c->cache_geom.nsub < NODE_CACHE_MAX_SUB) {
                 const size_t cnt = std::min<size_t>(c->last_deferred, 1u << 16);
                 std::vector<unsigned long long> info(cnt);
                 HIP_TRY(hipMemcpy(info.data(), c->d_defer_info, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -406,20 +418,85 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     }
     if (use_cache) {
         const int gw = L.gk_points == 15 ? 16 : 32;
-        L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
-        HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
+        // Omegas whose integrals are very long (hundreds of intervals each: strongly damped
+        // points) are latency-bound on a single lane.  They go to the lanes-are-nodes kernel,
+        // which advances all nodes of an interval in parallel and also reads the node cache;
+        // it runs next to the cached kernel on a second stream.
+        std::vector<int>& lm = c->h_longmask;
+        lm.assign(nbatch, 0);
+        int n_long = 0;
+        if (cost) {
+            const double per_integral = (double)c->npairs * c->nm;
+            std::vector<int> keep;
+            for (int b : idx) {
+                if ((double)cost[b] > c->long_threshold * per_integral)
+                    lm[b] = 1, ++n_long;
+                else
+                    keep.push_back(b);
+            }
+            idx.swap(keep);
+        }
+        // Omega chunks of unequal size for the rest.  Every lane walks ONE omega's trees, so an
+        // omega whose integrals need 3x the intervals keeps its lane busy 3x longer than its
+        // neighbours'.  A chunk of n omegas gives each of them gw/n lanes per group: expensive
+        // omegas go into small chunks, cheap ones share a chunk 16 (32) at a time.  idx is
+        // sorted by cost, most expensive first, so chunk capacities only grow along the list.
+        std::vector<int>& ch = c->h_chunks;
+        ch.clear();
+        if (!idx.empty()) {
+            std::vector<unsigned long long> cs;
+            for (int b : idx) cs.push_back(cost ? cost[b] : 1ull);
+            std::vector<unsigned long long> sorted = cs;
+            std::sort(sorted.begin(), sorted.end());
+            const double typical = (double)std::max<unsigned long long>(sorted[sorted.size() / 2], 1ull);
+            size_t q = 0;
+            while (q < idx.size()) {
+                int cap = gw;
+                while (cap > 1 && (double)cs[q] * cap > typical * gw * 1.5) cap >>= 1;
+                const int n = (int)std::min<size_t>((size_t)cap, idx.size() - q);
+                ch.push_back((int)q);
+                ch.push_back(n);
+                q += (size_t)n;
+            }
+        }
+        const int nchunks = (int)ch.size() / 2;
+        const int n_lane = (int)idx.size();
+        L.items_per_group = items_per_group_for(c, nchunks > 0 ? nchunks : 1);
+        if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_lane, hipMemcpyHostToDevice, c->stream));
+        if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
         c->last_fill_mode = 2;
-        {
+        if (n_long) {
+            // fork: the long-integral omegas on stream2, concurrently with the cached kernel
+            if (!c->stream2) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            HIP_TRY(hipMemcpyAsync(c->d_longmask, lm.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            AssembleLaunch L2 = L;
+            L2.active = c->d_longmask;
+            L2.items_per_group = items_per_group_for(c, n_long);
+            {
+                ScopedSpan s2(c, K_DEFER, c->stream2, true);
+                HIP_TRY(launch_assemble(L2, c->stream2, &c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab));
+            }
+            HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+        }
+        if (n_lane) {
             ScopedSpan s(c, K_ASM);
             HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale,
                                            c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx,
-                                           n_act, c->stream));
+                                           n_lane, c->d_chunks, nchunks, c->stream));
         }
-        {
+        if (n_lane) {
             ScopedSpan s(c, K_DEFER);
-            HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, c->stream));
+            HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
+                                         c->d_recs_ext, c->d_ttab, c->stream));
         }
+        if (n_long) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
             (void)hipMemcpy(&cnt, c->d_worklist_count, sizeof cnt, hipMemcpyDeviceToHost);
@@ -490,6 +567,7 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->device = device;
     if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
     if (const char* e = std::getenv("EMME_NODE_CACHE_GB")) c->cache_budget_gb = std::atof(e);
+    if (const char* e = std::getenv("EMME_LONG_THRESHOLD")) c->long_threshold = std::atof(e);
     const int N = p->npoints;
     c->N = N;
     const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
@@ -551,7 +629,8 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         if (p) (void)hipFree((void*)p);
     };
     F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
-        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_M), F(c->d_Mold),
+        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_chunks), F(c->d_longmask), F(c->d_M),
+        F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (int k = 0; k < 2; ++k) {
         F(c->d_recs[k]), F(c->d_ttab[k]);
@@ -559,6 +638,9 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     }
     F(c->d_scale);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     delete c;

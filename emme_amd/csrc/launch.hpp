@@ -6,6 +6,17 @@
 
 namespace emme {
 
+// HBM cache of the omega-independent node records (assemble_cached.hip): the full bisection
+// tree down to depth dfull plus up to NODE_CACHE_MAX_SUB full subtrees (root depth rd, root
+// path rp, down to depth dd).  Subtree 0 shares the main buffer with the full tree; the others
+// are added at run time, each in its own buffer.
+constexpr int NODE_CACHE_MAX_SUB = 6;
+struct NodeCacheGeom {
+    int dfull;
+    int nsub;
+    int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB];
+    unsigned long long rp[NODE_CACHE_MAX_SUB];
+};
 struct AssembleLaunch {
     DevParams P;
     int gk_points;       // 15 or 31
@@ -24,23 +35,16 @@ struct AssembleLaunch {
     int* status;         // device
     unsigned long long* rounds = nullptr;  // device [1], omega-lane kernel diagnostic
 };
-hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream);
+// lanes-are-nodes kernel; with a node cache (g != null) it reads cached records where they exist
+hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const NodeCacheGeom* g = nullptr,
+                           const void* const recs[2] = nullptr,
+                           const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1] = nullptr,
+                           const void* const ttab[2] = nullptr);
 // omega-lane form (assemble_wl.hip): the n_act batch items listed in act_idx (device) share
 // the omega-independent node data; L.active is ignored.
 hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n_act,
                               hipStream_t stream);
 
-// HBM cache of the omega-independent node records (assemble_cached.hip): the full bisection
-// tree down to depth dfull plus up to NODE_CACHE_MAX_SUB full subtrees (root depth rd, root
-// path rp, down to depth dd).  Subtree 0 shares the main buffer with the full tree; the others
-// are added at run time, each in its own buffer.
-constexpr int NODE_CACHE_MAX_SUB = 6;
-struct NodeCacheGeom {
-    int dfull;
-    int nsub;
-    int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB];
-    unsigned long long rp[NODE_CACHE_MAX_SUB];
-};
 // part -1 = main buffer (full tree + subtree 0), part k >= 0 = run-time subtree k+1
 size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g, int part);
 size_t node_ttab_bytes(int gk_points, int max_intervals);
@@ -53,10 +57,14 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
                                   const void* const ttab[2], const double* scale,
                                   unsigned long long* worklist, unsigned int* worklist_count,
                                   unsigned long long* defer_info, const int* act_idx, int n_act,
+                                  const void* chunks /*int2[nchunks]: (first, size)*/, int nchunks,
                                   hipStream_t stream);
 // integrals deferred by the cached kernel, recomputed by the lanes-are-nodes kernel
 hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
-                                const unsigned int* count, hipStream_t stream);
+                                const unsigned int* count, const NodeCacheGeom* g,
+                                const void* const recs[2],
+                                const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                                const void* const ttab[2], hipStream_t stream);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,

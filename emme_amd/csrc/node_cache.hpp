@@ -1,0 +1,84 @@
+// node_cache.hpp -- layout of the HBM cache of omega-independent node records, shared by the
+// kernel that fills it / reads it (assemble_cached.hip) and by the list-mode fill kernel
+// (assemble.hip), which uses cached records wherever they exist.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "launch.hpp"
+
+namespace emme {
+namespace {
+
+struct NodeRec {  // 48 bytes per (item, interval, node); T = i t~ does not depend on the pair
+    double2 A0, Q1, Q0;  // and lives in a small table shared by all items (L2-resident)
+};
+
+// Which intervals are cached.  Adaptive trees of this integrand are shallow almost everywhere;
+// damped omegas force narrow, deep refinements, mostly towards t -> infinity (x -> pi/2).  The
+// cache therefore holds the FULL tree down to depth `dfull` plus a list of full SUBTREES, each
+// given by its root (depth rd, path rp) and the depth dd it reaches.  Subtree 0 is fixed (under
+// the rightmost depth-5 node) and lives with the full tree in the main buffer; further
+// subtrees are added by the host at run time around intervals that integrals were found to
+// need (see emme_capi.hip), each in a buffer of its own.
+struct CacheGeom {
+    int dfull;
+    int nsub;
+    int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB], base[NODE_CACHE_MAX_SUB];
+    unsigned long long rp[NODE_CACHE_MAX_SUB];
+    __host__ __device__ int ni_full() const { return (2 << dfull) - 1; }
+    __host__ __device__ int ni_sub(int k) const { return (2 << (dd[k] - rd[k])) - 1; }
+    __host__ __device__ int ni_main() const { return ni_full() + (nsub > 0 ? ni_sub(0) : 0); }
+    __host__ __device__ int ni() const { return nsub > 0 ? base[nsub - 1] + ni_sub(nsub - 1) : ni_full(); }
+    // record slot of interval (depth, path), or -1 if it is not cached; *which = -1 for the
+    // main buffer, k-1 for the extension buffer of subtree k >= 1
+    __device__ int slot(int depth, unsigned long long path, int& which) const {
+        which = -1;
+        if (depth <= dfull) return (1 << depth) - 1 + (int)path;
+        for (int k = 0; k < nsub; ++k) {
+            if (depth <= dd[k] && depth >= rd[k]) {
+                const int sd = depth - rd[k];
+                if ((path >> sd) == rp[k]) {
+                    which = k - 1;
+                    return base[k] + (1 << sd) - 1 + (int)(path & ((1ull << sd) - 1ull));
+                }
+            }
+        }
+        return -1;
+    }
+    // inverse of slot() for the builder: part -1 = main buffer, part k >= 0 = subtree k+1
+    __device__ void interval(int part, int rel, int& depth, unsigned long long& path) const {
+        int k = part + 1;
+        if (part < 0) {
+            if (rel < ni_full()) {
+                depth = 31 - __clz(rel + 1);
+                path = (unsigned long long)(rel + 1) - (1ull << depth);
+                return;
+            }
+            rel -= ni_full();
+            k = 0;
+        }
+        const int sd = 31 - __clz(rel + 1);
+        depth = rd[k] + sd;
+        path = (rp[k] << sd) | ((unsigned long long)(rel + 1) - (1ull << sd));
+    }
+};
+
+
+inline CacheGeom make_geom(const NodeCacheGeom& g) {
+    CacheGeom c;
+    c.dfull = g.dfull;
+    c.nsub = g.nsub;
+    int base = c.ni_full();
+    for (int k = 0; k < NODE_CACHE_MAX_SUB; ++k) {
+        c.rd[k] = k < g.nsub ? g.rd[k] : 0;
+        c.dd[k] = k < g.nsub ? g.dd[k] : 0;
+        c.rp[k] = k < g.nsub ? g.rp[k] : 0;
+        c.base[k] = base;
+        if (k < g.nsub) base += c.ni_sub(k);
+    }
+    return c;
+}
+
+
+}  // namespace
+}  // namespace emme
