@@ -101,6 +101,11 @@ def load():
     lib.emme_newton_step_batch.argtypes = [P, P, P, C.c_int, P, P, C.c_int, P]
     lib.emme_solve_roots.argtypes = [P, P, C.c_int, C.c_double, C.c_int, P, P, P, P]
     lib.emme_ctx_get_matrix.argtypes = [P, C.c_int, P]
+    lib.emme_null_vector.argtypes = [P, C.c_int, P]
+    lib.emme_run_json.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.emme_free.argtypes = [C.c_void_p]
+    lib.emme_free.restype = None
+    lib.emme_scan_values.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, P, P, C.c_int]
     _LIB = lib
     return lib
 
@@ -162,6 +167,38 @@ def tables(p: Params):
 
 def weight(n, i, j) -> float:
     return load().emme_weight(n, i, j)
+
+
+def null_vector(M) -> np.ndarray:
+    """nullSpace (reference include/solver.h:58-112) of a complex symmetric matrix."""
+    M = np.ascontiguousarray(M, dtype=np.complex128)
+    v = np.zeros(M.shape[0], dtype=np.complex128)
+    _check(load().emme_null_vector(M.ctypes.data, M.shape[0], v.ctypes.data))
+    return v
+
+
+def scan_values(head, step, tail):
+    """The values (and turning flags) one {head, step, tail} axis visits (src/main.cpp:139-172)."""
+    if isinstance(tail, (list, tuple)):
+        t0, t1 = tail
+    else:
+        t0, t1 = tail, head + 0.5 * np.copysign(step, head - tail)
+    vals = np.zeros(100000)
+    turn = np.zeros(100000, dtype=np.int32)
+    n = load().emme_scan_values(head, step, t0, t1, vals.ctypes.data, turn.ctypes.data, len(vals))
+    return vals[:n].copy(), turn[:n].copy()
+
+
+def run_json(text: str, matrix_dir: str | None = None) -> dict:
+    """The reference's main() on an input.json text (src/main.cpp:182-338); returns output.json."""
+    import json
+    out = C.c_void_p()
+    rc = load().emme_run_json(text.encode(), matrix_dir.encode() if matrix_dir else None, C.byref(out))
+    _check(rc)
+    try:
+        return json.loads(C.string_at(out).decode())
+    finally:
+        load().emme_free(out)
 
 
 def _c128(a, shape=None):

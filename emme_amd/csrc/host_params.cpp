@@ -15,6 +15,7 @@
 
 namespace emme {
 void set_error(const std::string& msg);  // emme_capi.hip
+int params_from_value(const JsonValue& root, emme_params_t* out);
 }
 
 namespace {
@@ -146,6 +147,20 @@ int emme_params_from_json(const char* json_text, emme_params_t* out) {
     if (!json_text || !out) return EMME_EINVAL;
     try {
         const JsonValue root = emme::json_parse(json_text);
+        return emme::params_from_value(root, out);
+    } catch (const std::exception& e) {
+        emme::set_error(e.what());
+        return EMME_EJSON;
+    }
+}
+
+}  // extern "C"
+
+namespace emme {
+// Parameters::generate on an already parsed document (used by the scan driver, which edits
+// the document between solves)
+int params_from_value(const JsonValue& root, emme_params_t* out) {
+    try {
         if (!root.is_object()) throw std::runtime_error("top-level JSON value must be an object");
         emme_params_t p;
         std::memset(&p, 0, sizeof p);
@@ -216,6 +231,9 @@ int emme_params_from_json(const char* json_text, emme_params_t* out) {
         return EMME_EJSON;
     }
 }
+}  // namespace emme
+
+extern "C" {
 
 double emme_weight(int n, int i, int j) {
     // src/singularity_handler.cpp:4-20: end-corrected weights near the diagonal, 1

@@ -123,6 +123,24 @@ int emme_solve_roots(emme_ctx_t* ctx, const double* guesses, int n, double tol, 
 /* Copy M(omega_final) of item b of the last emme_solve_roots call (dim*dim complex). */
 int emme_ctx_get_matrix(emme_ctx_t* ctx, int b, double* M_host);
 
+/* nullSpace (reference include/solver.h:58-112): the right singular vector of the smallest
+ * singular value of the n x n complex matrix M (row-major), by inverse iteration on M^H M.
+ * Same vector as the reference's SVD result up to the arbitrary complex phase. Host pointers. */
+int emme_null_vector(const double* M, int n, double* vec /* 2n doubles */);
+
+/* The reference's driver (src/main.cpp:182-338) on an input.json TEXT: one solve, or a
+ * parameter scan over every key written {head, step, tail}, with omega continuation.
+ * matrix_dir (may be NULL): directory for the raw eigenMatrix .bin files (must exist, like the
+ * reference's eigenMatrics/).  *output_text receives the output.json text (release with
+ * emme_free).  Per-point failures become {"eigenvalue":"NaN","reason":...} records. */
+int emme_run_json(const char* input_text, const char* matrix_dir, char** output_text);
+void emme_free(void* p);
+/* Values one {head, step, tail:[tail0, tail1]} axis visits, in order (reference
+ * src/main.cpp:139-172); turning_flags[k] = 1 where the sweep restarts from the head in the
+ * other direction.  Returns the number of values (<= max_values). */
+int emme_scan_values(double head, double step, double tail0, double tail1, double* values,
+                     int* turning_flags, int max_values);
+
 #ifdef __cplusplus
 }
 #endif

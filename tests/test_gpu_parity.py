@@ -322,3 +322,45 @@ def test_root_search_same_in_every_kernel_mode(emme, oracle, mode, monkeypatch):
     for b in (0, 3):
         r_or, its_or, _, _ = oracle.solve_root(po, complex(guesses[b]))
         assert iters[b] == len(its_or) and abs(roots[b] - r_or) <= TOL_W
+
+
+# ---- the reference's driver (src/main.cpp) through emme_run_json --------------------------
+def test_run_json_scan_with_continuation(emme, oracle, tmp_path):
+    d = example_tokamak(npoints=24, omega_d_coeff={"head": 1.01, "tail": [0.81, 1.01], "step": 0.1})
+    out = emme.run_json(emme.json_text(d), str(tmp_path))
+    unit = out["result"]["omega_d_coeff"]
+    assert unit["scan_key"] == "omega_d_coeff"
+    assert np.allclose(unit["scan_values"], [1.01, 0.91, 0.81])
+    guess = -0.8 + 0.25j
+    for rec, val in zip(unit["scan_result"], unit["scan_values"]):
+        po = oracle.params(example_tokamak(npoints=24, omega_d_coeff=val))
+        r_or, its, Mo, _ = oracle.solve_root(po, guess, want_matrix=True)
+        got = complex(*rec["eigenvalue"])
+        assert abs(got - r_or) <= 2e-6 * abs(r_or)  # text output carries 6 significant digits
+        assert rec["scan_value"] == pytest.approx(val)
+        # raw matrix file: dim^2 complex128, row-major (src/main.cpp:61-63)
+        M = np.fromfile(rec["eigenMatrix"], dtype=np.complex128).reshape(24, 24)
+        assert np.abs(M - Mo).max() <= 1e-8 * np.abs(Mo).max()
+        # eigenvector = null vector of M(root), up to a phase
+        v = np.array([complex(*z) for z in rec["eigenvector"]])
+        want = np.linalg.svd(Mo)[2][-1].conj()
+        assert abs(abs(np.vdot(want, v)) - 1.0) < 1e-4
+        guess = r_or  # omega continuation (src/main.cpp:78)
+    assert "run_time" in out and out["input"]["npoints"] == 24
+
+
+def test_run_json_single_and_error_records(emme, tmp_path):
+    d = example_tokamak(npoints=16)
+    out = emme.run_json(emme.json_text(d), str(tmp_path))
+    rec = out["result"]["(None)"]["scan_result"][0]
+    assert len(rec["eigenvector"]) == 16 and os.path.exists(os.path.join(str(tmp_path), "eigenMatrix.bin"))
+    # a failing scan point becomes a NaN record with the reason (src/main.cpp:311-318)
+    bad = example_tokamak(npoints=16, integration_start_points=21,
+                          omega_d_coeff={"head": 1.01, "tail": [0.91, 1.01], "step": 0.1})
+    out = emme.run_json(emme.json_text(bad), None)
+    recs = out["result"]["omega_d_coeff"]["scan_result"]
+    assert len(recs) == 2 and all(r["eigenvalue"] == "NaN" for r in recs)
+    assert recs[0]["reason"] == "integration_start_points should be 15 or 31"
+    with pytest.raises(emme.EmmeError) as e:
+        emme.run_json(emme.json_text(dict(d, method="PIC")), None)
+    assert "Method 'PIC' is not supported" in e.value.reason

@@ -133,3 +133,34 @@ def test_unsupported_start_points_rejected(emme):
     with pytest.raises(emme.EmmeError) as e:
         emme.Context(p)
     assert e.value.reason == "integration_start_points should be 15 or 31"
+
+
+def test_null_vector_matches_svd(emme):
+    """nullSpace (include/solver.h:58-112): last right singular vector, up to a phase."""
+    rng = np.random.default_rng(3)
+    n = 40
+    # complex symmetric and nearly singular, like M(omega) at a root: X diag(d) X^T
+    X = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    d = rng.uniform(0.5, 2.0, size=n) * np.exp(1j * rng.uniform(0, 6.28, size=n))
+    d[-1] = 1e-9
+    A2 = (X * d) @ X.T
+    assert np.allclose(A2, A2.T)
+    want = np.linalg.svd(A2)[2][-1].conj()
+    got = emme.null_vector(A2)
+    assert abs(abs(np.vdot(want, got)) - 1.0) < 1e-6
+    assert abs(np.linalg.norm(got) - 1.0) < 1e-12
+    assert np.linalg.norm(A2 @ got) <= 1e-7 * np.linalg.norm(A2)
+
+
+def test_scan_generator_sequence(emme):
+    """{head, step, tail:[l,r]} sweeps towards l, then restarts from head towards r; the
+    0.01*step fuzz decides the end points (src/main.cpp:139-172)."""
+    v, t = emme.scan_values(1.01, 0.1, [0.01, 1.01])  # the shipped input-example.json axis
+    assert len(v) == 11 and t.sum() == 0
+    assert np.allclose(v, 1.01 - 0.1 * np.arange(11))
+    v, t = emme.scan_values(0.5, 0.1, [0.3, 0.8])
+    assert np.allclose(v, [0.5, 0.4, 0.3, 0.6, 0.7, 0.8]) and list(t) == [0, 0, 0, 1, 0, 0]
+    v, t = emme.scan_values(0.02, -0.001, [0.02, 0.02])  # the stellarator example: one point
+    assert np.allclose(v, [0.02])
+    v, t = emme.scan_values(1.0, 0.25, 0.5)  # scalar tail: other tail = head + step/2 -> unused
+    assert np.allclose(v, [1.0, 0.75, 0.5])
