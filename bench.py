@@ -141,8 +141,10 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -158,13 +160,13 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
         roots, iters, info = ctx.solve_roots(guesses)
-        allroots = gather_roots(roots, iters, info, world)  # one all-gather (RCCL) per step
+        allroots = gather_roots(roots, iters, info, world, force_dist=use_dist)  # ONE all-gather (RCCL)
         return roots, iters, info, allroots
 
     for _ in range(args.warmup):
@@ -183,7 +185,7 @@ def main():
 
     stats = torch.tensor([dt, float(points), float((info == 0).sum()), float(len(guesses))],
                          dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -265,7 +267,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

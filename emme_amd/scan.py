@@ -33,11 +33,11 @@ def unpack(packed: np.ndarray):
     return packed[:, 0] + 1j * packed[:, 1], packed[:, 2].astype(np.int32), packed[:, 3].astype(np.int32)
 
 
-def gather_roots(roots, iters, info, world: int, n_total: int | None = None):
+def gather_roots(roots, iters, info, world: int, n_total: int | None = None, force_dist: bool = False):
     """All-gather {w_re, w_im, iters, info} (32 B per item) and restore the global item
     order of `shard`.  Returns (roots, iters, info) for ALL items on every rank."""
     local = pack(roots, iters, info)
-    if world == 1:
+    if world == 1 and not force_dist:
         return unpack(local)
     import torch
     import torch.distributed as dist
