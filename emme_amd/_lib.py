@@ -98,6 +98,7 @@ def load():
     lib.emme_ctx_profile_read.argtypes = [P, C.POINTER(Profile), C.c_int]
     lib.emme_assemble_batch.argtypes = [P, P, C.c_int, P, P]
     lib.emme_trace_solve_batch.argtypes = [P, C.c_int, C.c_int, P, P, P, P]
+    lib.emme_qr_secant_batch.argtypes = [P, C.c_int, C.c_int, P, P, P, P]
     lib.emme_newton_step_batch.argtypes = [P, P, P, C.c_int, P, P, C.c_int, P]
     lib.emme_solve_roots.argtypes = [P, P, C.c_int, C.c_double, C.c_int, P, P, P, P]
     lib.emme_ctx_get_matrix.argtypes = [P, C.c_int, P]
@@ -280,7 +281,23 @@ class Context:
                                                tr.ctypes.data, info.ctypes.data))
         return tr, info
 
-    # newtonTraceSecantIteration (include/solver.h:113-160), batched
+    # the linear algebra of newtonQRSecantIteration (include/solver.h:244-370): q with
+    # domega = -1/q, for arbitrary square A (= M) and B (= M')
+    def qr_secant(self, A, B):
+        A = _c128(A)
+        B = _c128(B)
+        if A.ndim == 2:
+            A, B = A[None], B[None]
+        A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
+        nb, n, _ = A.shape
+        q = np.zeros(nb, dtype=np.complex128)
+        info = np.zeros(nb, dtype=np.int32)
+        _check(self.lib.emme_qr_secant_batch(self.h, n, nb, A.ctypes.data, B.ctypes.data,
+                                             q.ctypes.data, info.ctypes.data))
+        return q, info
+
+    # newtonTraceSecantIteration / newtonQRSecantIteration (include/solver.h:113-160, 210-383),
+    # batched; method: 0 trace-secant, 1 QR-secant
     def newton_step(self, omegas, M, Mp, method=0):
         w = _c128(np.atleast_1d(omegas)).copy()
         nb = w.shape[0]

@@ -220,6 +220,34 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
     return launch_trace_solve(n, nbatch, A, B, active, tr, info, c->stream);
 }
 
+// One Newton linear step on the batch: leaves tr[b] with domega = -1/tr[b].
+//   trace-secant (include/solver.h:113-160): work <- M, LU of [work | Mp], tr(M^-1 M')
+//   QR-secant    (include/solver.h:210-383): work <- M^T, pivoted QR of work, t_n / R_nn
+hipError_t linear_step(emme_ctx* c, int method, int n, int nbatch, const double* M, double* work,
+                       double* Mp, const int* active, double* tr, int* info) {
+    const size_t mbytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
+    if (method == EMME_METHOD_QR_SECANT) {
+        hipError_t e = launch_transpose(n, nbatch, M, work, active, c->stream);
+        if (e != hipSuccess) return e;
+        return launch_qr_secant(n, nbatch, work, Mp, active, tr, info, c->stream);
+    }
+    hipError_t e = hipMemcpyAsync(work, M, mbytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    return trace_solve(c, n, nbatch, work, Mp, active, tr, info);
+}
+
+int check_method(const emme_ctx* c, int method) {
+    if (method != EMME_METHOD_TRACE_SECANT && method != EMME_METHOD_QR_SECANT) {
+        set_error("unknown iteration method");
+        return EMME_EINVAL;
+    }
+    if (method == EMME_METHOD_QR_SECANT && c->dim > 1024) {
+        set_error("QR-secant step: matrix dimension above 1024 is not supported");
+        return EMME_ECONFIG;
+    }
+    return EMME_OK;
+}
+
 int items_per_group_for(const emme_ctx* c, long units) {
     // enough lane groups to give every SIMD several waves, but a few integrals per group
     // when the batch is large so the start-up cost (table staging) is amortised
@@ -762,15 +790,67 @@ int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* 
     return EMME_OK;
 }
 
-int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nbatch, double* M,
-                           double* Mp, int method, int* info) {
-    if (!c || !omega || !domega || !M || !Mp || !info || nbatch < 1) return EMME_EINVAL;
-    if (method != EMME_METHOD_TRACE_SECANT) {
-        set_error("only iteration_method \"TraceSecant\" is implemented on the device");
+int emme_qr_secant_batch(emme_ctx_t* c, int n, int nbatch, const double* A, const double* B,
+                         double* q, int* info) {
+    if (!c || !A || !B || !q || !info || n < 1 || nbatch < 1) return EMME_EINVAL;
+    if (n > 1024) {
+        set_error("QR-secant step: matrix dimension above 1024 is not supported");
         return EMME_ECONFIG;
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_batch(c, nbatch);
+    if (rc) return rc;
+    const bool devA = is_device_ptr(A), devB = is_device_ptr(B);
+    if (devA != devB) {
+        set_error("A and B must both be host or both be device pointers");
+        return EMME_EINVAL;
+    }
+    const size_t bytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
+    double *dA = nullptr, *dB = nullptr, *dW = nullptr;
+    auto release = [&]() {
+        if (dW) (void)hipFree(dW);
+        if (!devA && dA) (void)hipFree(dA);
+        if (!devA && dB) (void)hipFree(dB);
+    };
+    if (hipMalloc((void**)&dW, bytes) != hipSuccess) {
+        set_error("hipMalloc failed");
+        return EMME_ENOMEM;
+    }
+    if (devA) {
+        dA = const_cast<double*>(A), dB = const_cast<double*>(B);
+    } else {
+        if (hipMalloc((void**)&dA, bytes) != hipSuccess || hipMalloc((void**)&dB, bytes) != hipSuccess) {
+            release();
+            set_error("hipMalloc failed");
+            return EMME_ENOMEM;
+        }
+        (void)hipMemcpyAsync(dA, A, bytes, hipMemcpyHostToDevice, c->stream);
+        (void)hipMemcpyAsync(dB, B, bytes, hipMemcpyHostToDevice, c->stream);
+    }
+    hipError_t e;
+    {
+        ScopedSpan s(c, K_LIN);
+        e = launch_transpose(n, nbatch, dA, dW, nullptr, c->stream);
+        if (e == hipSuccess) e = launch_qr_secant(n, nbatch, dW, dB, nullptr, c->d_tr, c->d_info, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(q, c->d_tr, sizeof(double) * 2 * nbatch, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    release();
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        return EMME_EDEVICE;
+    }
+    return EMME_OK;
+}
+
+int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nbatch, double* M,
+                           double* Mp, int method, int* info) {
+    if (!c || !omega || !domega || !M || !Mp || !info || nbatch < 1) return EMME_EINVAL;
+    int rc = check_method(c, method);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = ensure_batch(c, nbatch);
     if (rc) return rc;
     const bool dev = is_device_ptr(M);
     if (dev != is_device_ptr(Mp)) {
@@ -796,11 +876,10 @@ int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nba
         // consumes a scratch copy so M_old survives for the secant update
         ScopedSpan s(c, K_OTHER);
         HIP_TRY(hipMemcpyAsync(c->d_Mold, dM, mbytes, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_work, dM, mbytes, hipMemcpyDeviceToDevice, c->stream));
     }
     {
         ScopedSpan s(c, K_LIN);
-        HIP_TRY(trace_solve(c, c->dim, nbatch, c->d_work, dMp, nullptr, c->d_tr, c->d_info));
+        HIP_TRY(linear_step(c, method, c->dim, nbatch, dM, c->d_work, dMp, nullptr, c->d_tr, c->d_info));
     }
     {
         ScopedSpan s(c, K_OTHER);
@@ -832,12 +911,11 @@ int emme_newton_step_batch(emme_ctx_t* c, double* omega, double* domega, int nba
 int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, int step_limit,
                      double* roots, int* iters, int* info, double* iterates) {
     if (!c || !guesses || !roots || !iters || !info || n < 1 || step_limit < 0) return EMME_EINVAL;
-    if (c->p.iteration_method != EMME_METHOD_TRACE_SECANT) {
-        set_error("only iteration_method \"TraceSecant\" is implemented on the device");
-        return EMME_ECONFIG;
-    }
+    const int method = c->p.iteration_method;  // src/main.cpp:45-49
+    int rc = check_method(c, method);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_batch(c, n);
+    rc = ensure_batch(c, n);
     if (rc) return rc;
     rc = ensure_mats(c, n, 1 | 2 | 4 | 8);
     if (rc) return rc;
@@ -899,11 +977,10 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         {
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(hipMemcpyAsync(c->d_Mold, c->d_M, mbytes, hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->d_work, c->d_M, mbytes, hipMemcpyDeviceToDevice, c->stream));
         }
         {
             ScopedSpan s(c, K_LIN);
-            HIP_TRY(trace_solve(c, c->dim, n, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info));
+            HIP_TRY(linear_step(c, method, c->dim, n, c->d_M, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info));
         }
         {
             ScopedSpan s(c, K_OTHER);

@@ -75,6 +75,16 @@ size_t trace_solve_blocked_lds(int n);
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
                                       double* tr, int* info, hipStream_t stream);
 
+// QR-secant form of the step (linstep_qr.hip, reference include/solver.h:210-383): Wt holds the
+// TRANSPOSE of each matrix (destroyed), Mp the secant derivative (read only); writes
+// tr = t_n / R_nn so that domega = -1/tr = -R_nn / t_n; info = k > 0 when R11(k,k) == 0.
+size_t qr_secant_lds(int n);
+hipError_t launch_qr_secant(int n, int nbatch, double* Wt, const double* Mp, const int* active,
+                            double* tr, int* info, hipStream_t stream);
+// out_b = in_b^T for every active item (n x n complex, row-major)
+hipError_t launch_transpose(int n, int nbatch, const double* in, double* out, const int* active,
+                            hipStream_t stream);
+
 // domega = -1/tr; omega += domega; iters += 1; active = !(|domega| < tol |omega|) && info == 0
 // (include/solver.h:139-140, src/main.cpp:53-56). `iterates` (nullable) records omega.
 hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,

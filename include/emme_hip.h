@@ -103,7 +103,9 @@ int emme_assemble_batch(emme_ctx_t* ctx, const double* omega, int nbatch, double
  *   in : omega[b], M[b] = M(omega[b]), Mp[b] = M'(omega[b])
  *   out: domega[b] = -1/tr(M^-1 M'), omega[b] += domega[b], M[b] = M(new omega),
  *        Mp[b] = (M_new - M_old)/domega, info[b] (LAPACK convention).
- * method must be EMME_METHOD_TRACE_SECANT (QR-secant: EMME_ECONFIG). */
+ * method: EMME_METHOD_TRACE_SECANT as above; EMME_METHOD_QR_SECANT replaces the step by the
+ * reference's newtonQRSecantIteration (include/solver.h:210-383): domega = -R_nn / (Q^H M' v)_n
+ * from the column-pivoted QR of M (info[b] = k > 0: R(k,k) == 0, the ztrtrs failure). */
 int emme_newton_step_batch(emme_ctx_t* ctx, double* omega, double* domega, int nbatch,
                            double* M, double* Mp, int method, int* info);
 
@@ -112,9 +114,17 @@ int emme_newton_step_batch(emme_ctx_t* ctx, double* omega, double* domega, int n
 int emme_trace_solve_batch(emme_ctx_t* ctx, int n, int nbatch, double* A, double* B, double* tr,
                            int* info);
 
+/* The QR-secant quotient alone, for any square A_b, B_b (nbatch*n*n complex, row-major, host or
+ * device, not modified; n <= 1024): with A P = Q R (Householder QR, LAPACK zgeqp3 pivoting),
+ * R11 y = r12, v = P [-y; 1], t = Q^H (B v):  q[b] = t_n / R_nn, so that the reference's step is
+ * domega = -1/q (include/solver.h:370).  q: 2*nbatch doubles (host); info: nbatch ints (host). */
+int emme_qr_secant_batch(emme_ctx_t* ctx, int n, int nbatch, const double* A, const double* B,
+                         double* q, int* info);
+
 /* Batched root search: for each guess g_b run the reference's solve-once sequence
  * (omega=0.99 g; M_old=M(omega); omega+=0.01 g; M; M'; then up to step_limit+1 Newton
- * steps, stopping when |domega| < tol*|omega|).  All arrays host.
+ * steps, stopping when |domega| < tol*|omega|).  The step is the one the context's
+ * iteration_method names (trace-secant or QR-secant, src/main.cpp:45-49).  All arrays host.
  * roots: 2n doubles; iters: n ints (Newton steps done); info: n ints (0 ok, k>0 singular
  * pivot k, EMME_ENUMERIC if that chain met a non-finite integral / the depth cap).
  * iterates (optional): n*(step_limit+1)*2 doubles, omega after every step, NaN padded. */

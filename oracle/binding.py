@@ -219,6 +219,66 @@ class Oracle:
                                            tr.ctypes.data)
         return complex(tr[0], tr[1]), info
 
+    # newtonQRSecantIteration's linear algebra (include/solver.h:210-383): the same LAPACK
+    # routines in the same order, through SciPy's LAPACK.  Returns (domega, info) with the
+    # reference's failure convention (info > 0: ztrtrs met a zero diagonal, :309-316).
+    # Parity at this boundary is unpinned in the sense of SURVEY.md §8(c): the reference holds
+    # no vectors for it and links whatever LAPACK the site provides.
+    @staticmethod
+    def qr_secant(A, B):
+        from scipy.linalg import lapack
+        A = np.array(A, dtype=np.complex128)
+        B = np.array(B, dtype=np.complex128)
+        n = A.shape[0]
+        # :240-251  column-major copy of M, zgeqp3 with all columns free
+        qr, jpvt, tau, _, info = lapack.zgeqp3(np.asfortranarray(A))
+        if info != 0:
+            raise RuntimeError("QR factorization with pivoting failed")
+        # :289-307  R11 y = r12
+        if n > 1:
+            y, info = lapack.ztrtrs(np.asfortranarray(np.triu(qr[:n - 1, :n - 1])),
+                                    qr[:n - 1, n - 1].copy(), lower=0, trans=0, unitdiag=0)
+            if info != 0:
+                return complex("nan"), int(info)
+        else:
+            y = np.zeros(0, dtype=np.complex128)
+        # :329-333  v = P [-y; 1]
+        v = np.zeros(n, dtype=np.complex128)
+        v[jpvt[:n - 1] - 1] = -y
+        v[jpvt[n - 1] - 1] = 1.0
+        # :340-346  t = M' v, summed in index order like the reference's loop
+        t = np.zeros(n, dtype=np.complex128)
+        for j in range(n):
+            t += B[:, j] * v[j]
+        # :361-363  t <- Q^H t
+        cq, _, info = lapack.zunmqr("L", "C", qr, tau, np.asfortranarray(t.reshape(n, 1)), n * n)
+        if info != 0:
+            raise RuntimeError("Q application failed")
+        return -qr[n - 1, n - 1] / cq[n - 1, 0], 0  # :370
+
+    # solve_once_eigen (src/main.cpp:19-80) with the QR-secant step, at Python level on top of
+    # the C restatement's fill.  Returns (root, iterates).
+    def solve_root_qr(self, p, guess: complex, nthreads=0):
+        w = 0.99 * guess  # EigenSolver ctor, include/solver.h:396-415
+        dw = 0.01 * guess
+        m_old, _ = self.assemble(p, w, nthreads)
+        w = w + dw
+        m, _ = self.assemble(p, w, nthreads)
+        mp = (m - m_old) / dw
+        its = []
+        for _ in range(p.iteration_step_limit + 1):  # src/main.cpp:43-57
+            m_old = m
+            dw, info = self.qr_secant(m, mp)
+            if info != 0:
+                return complex("nan"), np.array(its)
+            w = w + dw
+            m, _ = self.assemble(p, w, nthreads)
+            mp = (m - m_old) / dw
+            its.append(w)
+            if abs(dw) < p.iteration_precision * abs(w):
+                break
+        return w, np.array(its)
+
     def solve_root(self, p, guess: complex, nthreads=0, recompute=0, want_matrix=False):
         nthreads = nthreads or os.cpu_count()
         root = np.zeros(2)

@@ -364,3 +364,97 @@ def test_run_json_single_and_error_records(emme, tmp_path):
     with pytest.raises(emme.EmmeError) as e:
         emme.run_json(emme.json_text(dict(d, method="PIC")), None)
     assert "Method 'PIC' is not supported" in e.value.reason
+
+
+# ---- QR-secant step (include/solver.h:210-383) ---------------------------------------------
+def _near_singular(rng, n, gap):
+    """Random complex matrix whose smallest singular value is `gap` times the others."""
+    a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    u, s, vh = np.linalg.svd(a)
+    s[-1] = gap * s[0]
+    return (u * s) @ vh
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 100, 256, 300, 512, 640])
+def test_qr_secant_quotient_matches_lapack_sequence(emme, oracle, n):
+    """Householder QR with zlaqp2's pivot rule + ztrtrs + zunmqr on the device vs the same
+    LAPACK calls on the host (oracle.qr_secant); all three register-width variants of the
+    kernel (n <= 256, <= 512, <= 1024), generic and nearly singular (the Newton regime)."""
+    rng = np.random.default_rng(100 + n)
+    nb = 4 if n <= 300 else 2
+    A = np.stack([_near_singular(rng, n, 1e-7) if b % 2 else
+                  rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n)) for b in range(nb)])
+    B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    with _ctx(emme, example_tokamak(npoints=16)) as ctx:
+        q, info = ctx.qr_secant(A, B)
+    assert (info == 0).all()
+    for b in range(nb):
+        dw, i_or = oracle.qr_secant(A[b], B[b])
+        assert i_or == 0
+        assert abs(-1.0 / q[b] - dw) <= 1e-9 * abs(dw), (n, b, -1.0 / q[b], dw)
+
+
+def test_qr_secant_zero_diagonal_info(emme, oracle):
+    """Two zero columns: R11 gets an exactly zero diagonal entry -> the ztrtrs failure
+    (include/solver.h:309-316) is reported per item; the other items are unaffected."""
+    rng = np.random.default_rng(5)
+    n = 12
+    A = rng.normal(size=(3, n, n)) + 1j * rng.normal(size=(3, n, n))
+    B = rng.normal(size=(3, n, n)) + 1j * rng.normal(size=(3, n, n))
+    A[1][:, 3] = 0.0
+    A[1][:, 7] = 0.0
+    with _ctx(emme, example_tokamak(npoints=16)) as ctx:
+        q, info = ctx.qr_secant(A, B)
+    _, i_or = oracle.qr_secant(A[1], B[1])
+    assert info[1] == i_or == n - 1 and np.isnan(q[1])
+    for b in (0, 2):
+        dw, _ = oracle.qr_secant(A[b], B[b])
+        assert info[b] == 0 and abs(-1.0 / q[b] - dw) <= 1e-9 * abs(dw)
+
+
+@pytest.mark.parametrize("em", [False, True])
+def test_newton_step_qr_matches_oracle(emme, oracle, em):
+    d = example_stellarator(npoints=12) if em else example_tokamak(npoints=24)
+    po = oracle.params(d)
+    g = (-1.656 + 2.49j) if em else (-0.8 + 0.25j)
+    w0, dw0 = 0.99 * g, 0.01 * g
+    m_old, _ = oracle.assemble(po, w0)
+    m, _ = oracle.assemble(po, w0 + dw0)
+    mp = (m - m_old) / dw0
+    dw_or, info_or = oracle.qr_secant(m, mp)
+    m_new, _ = oracle.assemble(po, w0 + dw0 + dw_or)
+    with _ctx(emme, d) as ctx:
+        w, dw, M, Mp, info = ctx.newton_step([w0 + dw0], m[None], mp[None], method=1)
+    assert info[0] == info_or == 0
+    assert abs(dw[0] - dw_or) <= TOL_W * abs(dw_or)
+    assert abs(w[0] - (w0 + dw0 + dw_or)) <= TOL_W
+    scale = np.abs(m_new).max()
+    assert np.abs(M[0] - m_new).max() <= 1e-7 * scale  # omega differs in the last digits
+    assert np.abs(Mp[0] - (m_new - m) / dw_or).max() <= 1e-6 * np.abs(Mp[0]).max()
+
+
+def test_solve_roots_qr_method(emme, oracle):
+    """iteration_method != "TraceSecant" selects the QR step (src/main.cpp:45-49); both
+    variants reach the same root."""
+    d = example_tokamak(npoints=32, iteration_method="QRSecant")
+    po = oracle.params(d)
+    guesses = [-0.8 + 0.25j, -0.7 + 0.3j]
+    with _ctx(emme, d) as ctx:
+        roots, iters, info, its = ctx.solve_roots(guesses, want_iterates=True)
+    with _ctx(emme, dict(d, iteration_method="TraceSecant")) as ctx:
+        roots_tr, _, _ = ctx.solve_roots(guesses)
+    assert (info == 0).all()
+    for b, g in enumerate(guesses):
+        w_or, its_or = oracle.solve_root_qr(po, g)
+        assert iters[b] == len(its_or)
+        assert np.abs(its[b][:len(its_or)] - its_or).max() <= 1e-8
+        assert abs(roots[b] - w_or) <= TOL_W
+        assert abs(roots[b] - roots_tr[b]) <= 1e-5 * abs(roots[b])
+
+
+def test_run_json_qr_method(emme, oracle, tmp_path):
+    d = example_tokamak(npoints=32, iteration_method="QR")
+    out = emme.run_json(emme.json_text(d), str(tmp_path))
+    ev = out["result"]["(None)"]["scan_result"][0]["eigenvalue"]
+    w_or, _ = oracle.solve_root_qr(oracle.params(d), complex(*d["initial_guess"]))
+    assert abs(complex(ev[0], ev[1]) - w_or) <= 2e-6 * abs(w_or)  # 6 significant digits
