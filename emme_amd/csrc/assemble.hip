@@ -14,6 +14,8 @@
 // constant along a diagonal).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "assemble_common.hpp"
 #include "launch.hpp"
 #include "node_cache.hpp"
@@ -44,6 +46,36 @@ struct AsmArgs {
     const NodeRec* recs_ext[2][NODE_CACHE_MAX_SUB - 1];
     const double2* ttab[2];
 };
+
+// Value of the integrand at one quadrature node when a node-record cache may hold the
+// interval: take the record (lane = node) wherever there is one and compute the node data on
+// the spot only for uncached intervals.  Used for integrals the cached kernel deferred and for
+// omegas whose integrals are so long that their serial latency matters more than throughput:
+// here all 15 (31) nodes of an interval advance in parallel.
+template <int GW>
+__device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned long long path,
+                                         long cache_item, int lane_in_group, double x,
+                                         const PairConst& pc, const OmegaConst& oc, int m) {
+    const int cls = oc.omi > 0.0 ? 0 : 1;
+    int which;
+    const int cslot = A.recs[cls] ? A.geom.slot(depth, path, which) : -1;
+    const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? A.recs[cls] : A.recs_ext[cls][which]);
+    NodeData d;
+    if (buf) {
+        const NodeRec rec =
+            which < 0 ? buf[(cache_item * A.geom.ni_main() + cslot) * GW + lane_in_group]
+                      : buf[(cache_item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
+                            lane_in_group];
+        const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
+        d.A0 = mk(rec.A0.x, rec.A0.y);
+        d.T = mk(tt.x, tt.y);
+        d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+        d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+    } else {
+        d = node_data(x, A.P, pc, oc.omi, m);
+    }
+    return node_eval(d, oc.omega);
+}
 
 template <int PTS, bool LIST>
 #ifndef EMME_ASM_MIN_WAVES
@@ -159,36 +191,10 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
         // abscissa scale * x + mid, rounded like the reference (no FMA contraction)
         const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
 
-        cd f;
-        const int cls = oc.omi > 0.0 ? 0 : 1;
-        if (LIST || A.recs[cls] != nullptr) {
-            // Node-record cache available: take the record (lane = node) wherever there is
-            // one and compute the node data on the spot only for uncached intervals.  Used
-            // for integrals the cached kernel deferred (LIST) and for omegas whose integrals
-            // are so long (hundreds of intervals) that their serial latency matters more than
-            // throughput: here all 15 (31) nodes of an interval advance in parallel.
-            int which;
-            const int cslot = A.recs[cls] ? A.geom.slot(depth, path, which) : -1;
-            const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? A.recs[cls] : A.recs_ext[cls][which]);
-            NodeData d;
-            if (buf) {
-                const long it = LIST ? (long)(A.worklist[item] & 0xffffffffull) : (long)item;
-                const NodeRec rec =
-                    which < 0 ? buf[(it * A.geom.ni_main() + cslot) * GW + lane_in_group]
-                              : buf[(it * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
-                                    lane_in_group];
-                const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
-                d.A0 = mk(rec.A0.x, rec.A0.y);
-                d.T = mk(tt.x, tt.y);
-                d.Q1 = mk(rec.Q1.x, rec.Q1.y);
-                d.Q0 = mk(rec.Q0.x, rec.Q0.y);
-            } else {
-                d = node_data(x, P, pc, oc.omi, m);
-            }
-            f = node_eval(d, oc.omega);
-        } else {
-            f = integrand(x, P, pc, oc, m);
-        }
+        const long cache_item = LIST ? (long)(A.worklist[item] & 0xffffffffull) : (long)item;
+        const cd f = (LIST || A.recs[oc.omi > 0.0 ? 0 : 1] != nullptr)
+                         ? node_value<GW>(A, depth, path, cache_item, lane_in_group, x, pc, oc, m)
+                         : integrand(x, P, pc, oc, m);
         const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
         const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
         ++my_intervals;
@@ -272,6 +278,190 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
     }
 }
 
+// ---- cooperative form for the deferred list ---------------------------------------------------
+// The few integrals the cached kernel defers are the long ones (up to thousands of intervals,
+// bisection depth ~19): walked by ONE lane group they take milliseconds each and set the
+// latency of the whole deferred pass.  Here a whole workgroup owns one integral: its NG lane
+// groups pop up to NG intervals per round from a shared LDS stack (the deepest NG, so the
+// stack stays bounded by NG * (depth + 1) like a depth-first walk), evaluate them in
+// parallel and push the children of the ones that split.  Which group gets which interval and
+// where children go is decided by prefix sums, never by timing, so the result is
+// deterministic; the accept/split rule of an interval depends only on that interval and on
+// abs_tol from the root (include/functions.h:231-247), so the set of intervals -- the tree --
+// is exactly the sequential one.  Only the order in which accepted pieces are added differs
+// (per-group partial sums, then a fixed-order total): a rounding-level change.
+struct CoopEnt {
+    double l, r;
+    unsigned long long path;
+    int depth, pad;
+};
+
+template <int PTS>
+__global__ __launch_bounds__(256) void k_assemble_coop(AsmArgs A) {
+    constexpr int GW = PTS == 15 ? 16 : 32;
+    constexpr int NG = 256 / GW;
+    constexpr int CAP = 1024;  // >= NG * (MAXD + 1)
+    constexpr int MAXD = 40;
+    extern __shared__ double lds_tab[];  // eta | g | b (3N doubles) | CoopEnt stack[CAP]
+    __shared__ int s_cnt[NG];
+    __shared__ double s_part[NG][2];
+    __shared__ int s_bad;
+
+    const DevParams& P = A.P;
+    const int N = P.N, dim = P.dim;
+    for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_tab[k] = A.tab[k];
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const double* eta = lds_tab;
+    const double* gtab = lds_tab + N;
+    const double* btab = lds_tab + 2 * N;
+    CoopEnt* stk = reinterpret_cast<CoopEnt*>(lds_tab + 3 * N + (3 * N & 1));
+
+    const int lane_in_group = threadIdx.x % GW;
+    const int grp = threadIdx.x / GW;
+    const GkLane gk = gk_lane<PTS>(lane_in_group);
+    const double qa = 0.0, qb = M_PI / 2.0;
+    const double inv_scale = 2. / (qb - qa);
+    const int nitems = (int)*A.worklist_count;
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const unsigned long long e = A.worklist[item];
+        const int it = (int)(e & 0xffffffffull);
+        const int b = (int)(e >> 32);
+        OmegaConst oc;
+        oc.omega = mk(A.omega[b].x, A.omega[b].y);
+        oc.omi = -copysign(1.0, oc.omega.x);
+        const int p = it / P.nm;
+        const int m = it - p * P.nm;
+        const ushort2 ij = A.pairs[p];
+        const int i = ij.x, j = ij.y;
+        const double dg = gtab[i] - gtab[j];
+        const PairConst pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], dg);
+
+        // one interval: GK estimate, error, accept/split (include/functions.h:203-208, 231-247)
+        double abs_tol = 0.0;
+        auto evaluate = [&](double l, double r, int depth, unsigned long long path, cd& integral,
+                            double& mid) -> bool {
+            mid = (r + l) / 2;
+            const double scale = (r - l) / 2;
+            const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
+            const cd f = node_value<GW>(A, depth, path, (long)it, lane_in_group, x, pc, oc, m);
+            const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
+            const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
+            const double dKx = Kx - Gx, dKy = Ky - Gy;
+            const double absK = sqrt(fma(Kx, Kx, Ky * Ky));
+            double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
+            integral = mk(Kx * scale, Ky * scale);
+            err *= scale;
+            const double rel_abs = P.rel_tol * (absK * scale);
+            if (abs_tol == 0.0) abs_tol = rel_abs;
+            return depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
+                   err > rel_abs + P.prec_goal;
+        };
+
+        // root: every group evaluates it (identical bits) so that all hold abs_tol
+        cd gsum = mk(0.0, 0.0);
+        int top = 0, n_intervals = 1, bad = 0;
+        {
+            cd integral;
+            double mid;
+            const bool split = evaluate(qa, qb, 0, 0ull, integral, mid);
+            if (split) {
+                if (threadIdx.x == 0) {
+                    stk[0] = CoopEnt{mid, qb, 1ull, 1, 0};
+                    stk[1] = CoopEnt{qa, mid, 0ull, 1, 0};
+                }
+                top = 2;
+            } else if (grp == 0) {
+                gsum = integral;
+            }
+        }
+        __syncthreads();
+
+        while (top > 0) {  // `top`, `n_intervals`, `bad` are block-uniform
+            const int n_take = top < NG ? top : NG;
+            const int base = top - n_take;
+            bool split = false;
+            CoopEnt en{};
+            double mid = 0.0;
+            if (grp < n_take) {
+                en = stk[top - 1 - grp];
+                cd integral;
+                split = evaluate(en.l, en.r, en.depth, en.path, integral, mid);
+                if (split && en.depth >= MAXD) split = false, bad = 1;
+                if (!split) gsum = gsum + integral;
+            }
+            if (lane_in_group == 0) s_cnt[grp] = split ? 2 : 0;
+            if (bad && lane_in_group == 0) s_bad = 1;
+            __syncthreads();  // all entries read, all counts visible
+            int above = 0, total = 0;
+#pragma unroll
+            for (int h = 0; h < NG; ++h) {
+                const int c = s_cnt[h];
+                total += c;
+                if (h > grp) above += c;
+            }
+            n_intervals += n_take;
+            int ntop = base + total;
+            if (ntop > CAP || n_intervals >= (1 << 18)) {  // flag and stop refining (block-uniform)
+                if (threadIdx.x == 0) s_bad = 1;
+                ntop = base;
+            } else if (split && lane_in_group == 0) {
+                // group 0's children end on top, left half above right half
+                stk[base + above] = CoopEnt{mid, en.r, 2 * en.path + 1, en.depth + 1, 0};
+                stk[base + above + 1] = CoopEnt{en.l, mid, 2 * en.path, en.depth + 1, 0};
+            }
+            top = ntop;
+            __syncthreads();
+        }
+
+        // total in fixed group order
+        if (lane_in_group == 0) s_part[grp][0] = gsum.x, s_part[grp][1] = gsum.y;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            cd sum = mk(0.0, 0.0);
+            for (int h = 0; h < NG; ++h) sum = sum + mk(s_part[h][0], s_part[h][1]);
+            cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));
+            int isbad = s_bad;
+            if (!(isfinite(kap.x) && isfinite(kap.y))) isbad = 1;
+            kap = kap + kappa_e(m, P, pc.de, dg, oc.omega);
+            double2* Mb = A.M + (size_t)b * dim * dim;
+            const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
+            double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
+            const cd rdw = Moldb ? rcp(mk(A.domega[b].x, A.domega[b].y)) : mk(0.0, 0.0);
+            auto store = [&](int rr, int cc, cd v) {
+                const size_t idx = (size_t)rr * dim + cc;
+                Mb[idx] = make_double2(v.x, v.y);
+                if (Moldb) {
+                    const double2 o = Moldb[idx];
+                    const cd d = (v - mk(o.x, o.y)) * rdw;
+                    Mpb[idx] = make_double2(d.x, d.y);
+                }
+            };
+            if (m == 0) {  // include/solver.h:448-453
+                const double w = pair_weight(i, j, N);
+                const cd v = (-(w * P.dx)) * kap;
+                store(i, j, v);
+                store(j, i, v);
+            } else if (m == 1) {  // include/solver.h:480-504
+                const cd v = P.dx * kap;
+                store(i, j + N, v);
+                store(j, i + N, -v);
+                store(i + N, j, -v);
+                store(j + N, i, v);
+            } else {
+                const cd v = P.dx * kap;
+                store(i + N, j + N, v);
+                store(j + N, i + N, v);
+            }
+            if (A.intervals) atomicAdd(&A.intervals[b], (unsigned long long)n_intervals);
+            if (isbad) A.status[b] = 1;
+            s_bad = 0;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const NodeCacheGeom* g,
@@ -352,6 +542,16 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     dim3 grid(2048), block(256);
+    static const bool one_group = std::getenv("EMME_DEFER_ONE_GROUP") != nullptr;
+    if (!one_group) {
+        // a workgroup per integral (see k_assemble_coop)
+        const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) + 1024 * sizeof(CoopEnt);
+        if (L.gk_points == 15)
+            hipLaunchKernelGGL((k_assemble_coop<15>), grid, block, lds, stream, A);
+        else
+            hipLaunchKernelGGL((k_assemble_coop<31>), grid, block, lds, stream, A);
+        return hipGetLastError();
+    }
     const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
                        (size_t)groups_per_block * 40 * sizeof(double2);
     if (L.gk_points == 15)

@@ -7,6 +7,7 @@ import emme_amd, torch
 from oracle.binding import example_tokamak
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+kind = sys.argv[3] if len(sys.argv) > 3 else "lu"   # "lu" (trace form) or "qr"
 rng = np.random.default_rng(0)
 A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n)); A = A + np.transpose(A, (0, 2, 1)) + 4 * np.eye(n)
 B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
@@ -17,10 +18,17 @@ tr = np.zeros(nb, dtype=np.complex128); info = np.zeros(nb, dtype=np.int32)
 def run():
     a = dA.clone(); b = dB.clone(); torch.cuda.synchronize()
     t = time.perf_counter()
-    rc = lib.emme_trace_solve_batch(ctx.h, n, nb, a.data_ptr(), b.data_ptr(), tr.ctypes.data, info.ctypes.data)
+    if kind == "qr":
+        rc = lib.emme_qr_secant_batch(ctx.h, n, nb, a.data_ptr(), b.data_ptr(), tr.ctypes.data, info.ctypes.data)
+    else:
+        rc = lib.emme_trace_solve_batch(ctx.h, n, nb, a.data_ptr(), b.data_ptr(), tr.ctypes.data, info.ctypes.data)
     torch.cuda.synchronize()
     return time.perf_counter() - t, rc
 run()
 ts = [run()[0] for _ in range(5)]
-want = np.trace(np.linalg.solve(A[0], B[0]))
-print(f"n={n} batch={nb}: {min(ts)*1e3:.2f} ms (median {np.median(ts)*1e3:.2f}); check rel err {abs(tr[0]-want)/abs(want):.1e}")
+if kind == "qr":
+    from oracle.binding import Oracle
+    want = -1.0 / Oracle.qr_secant(A[0], B[0])[0]
+else:
+    want = np.trace(np.linalg.solve(A[0], B[0]))
+print(f"{kind} n={n} batch={nb}: {min(ts)*1e3:.2f} ms (median {np.median(ts)*1e3:.2f}); check rel err {abs(tr[0]-want)/abs(want):.1e}")
