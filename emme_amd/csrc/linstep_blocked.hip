@@ -28,6 +28,8 @@ namespace {
 constexpr int BT = 1024;     // threads per workgroup
 constexpr int BW = BT / 64;  // waves
 constexpr int NB = 16;
+constexpr int LS = NB + 1;  // row stride of the L21 panel in LDS (double2 units)
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ cd ldg(const double2* p) {
     const double2 v = *p;
@@ -144,22 +146,21 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         }
         if (sh.info != 0) break;  // uniform (read after the last barrier of the panel)
 
-        // ---- publish the panel: multipliers -> LDS, U11 -> global, new row order ------------
+        // ---- publish the panel: U11 -> global, new row order, multipliers -> LDS -------------
         if (tid < nrem) {
-            physrow[tid] = myrow;
             pivof[tid] = mypiv;
             if (mypiv >= 0) {
                 // this row is pivot k0+mypiv: its panel entries from column mypiv on are U
 #pragma unroll
                 for (int c = 0; c < NB; ++c)
                     if (c >= mypiv && c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NB; ++c) panel[tid * NB + c] = make_double2(pr[c].x, pr[c].y);
             }
         }
         __syncthreads();
-        // new row order: the nbk pivots first (in pivot order), then the others, stable
+        // new row order: the nbk pivots first (in pivot order), then the others, stable; the
+        // multipliers of a non-pivot row go to LDS at its NEW position (the trailing update
+        // walks rows in that order), rows LS = NB + 1 entries apart (bank spread for the
+        // 16-row operand reads of the MFMA tiles)
         if (tid < nrem) {
             int pos;
             if (mypiv >= 0) {
@@ -172,6 +173,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
                     before += pivof[t] >= 0;
                 }
                 pos = nbk + (tid - before);
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    panel[(pos - nbk) * LS + c] = make_double2(pr[c].x, pr[c].y);
             }
             rowmap[k0 + pos] = myrow;
         }
@@ -206,33 +210,75 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
             }
         }
         __syncthreads();
-        // T2: stream every remaining row once; waves sharing a column chunk split the rows
-        if (nchunks > 0 && nrem > nbk) {
-            const int wpc = nchunks >= BW ? 1 : BW / nchunks;  // waves per chunk
-            const int qstride = nchunks >= BW ? BW : BW / wpc;
-            for (int q = wave / wpc; q < nchunks; q += qstride) {
-                const int part = wave % wpc;
-                const int J = J0 + q * 64 + lane;
-                const bool okc = J < 2 * n;
-                cd u[NB];
+        // T2: X(rows below the block, trailing columns) -= L21 * U12 on the matrix cores, one
+        //     16 x 16 tile per wave and trip: v_mfma_f64_16x16x4_f64, four k-steps, and per
+        //     k-step four products for the complex multiply-subtract
+        //         Xre += (-Lre) Ure + Lim Uim,   Xim += (-Lre) Uim + (-Lim) Ure.
+        //     Operand maps (one f64 per lane): A[i = lane & 15][k = lane >> 4],
+        //     B[k = lane >> 4][j = lane & 15]; C/D: column lane & 15, row (lane >> 4) + 4 r.
+        //     A tile's 16 x 16 B operand (U12) stays in registers across the row tiles.
+        {
+            const int nrows = nrem - nbk;
+            const int nrt = (nrows + 15) >> 4, nct = (ncols + 15) >> 4;
+            const int i16 = lane & 15, kq = lane >> 4;
+            int cur_ct = -1;
+            double ure[4], uim[4];
+            // the C tile of the NEXT trip is fetched before the products of the current one,
+            // so every wave keeps two tiles' worth of loads in flight
+            struct CTile {
+                d4 re, im;
+            };
+            // element (row 4 r + kq of row tile rt, column i16 of column tile ct), or null
+            auto tile_ptr = [&](int tile, int r) -> double2* {
+                const int ct = tile / nrt, rt = tile - ct * nrt;
+                const int J = J0 + ct * 16 + i16;
+                const int rr = rt * 16 + kq + 4 * r;
+                return (tile < nrt * nct && J < 2 * n && rr < nrows) ? elem(rowmap[k0 + nbk + rr], J) : nullptr;
+            };
+            auto fetch = [&](int tile, CTile& t) {
 #pragma unroll
-                for (int kk = 0; kk < NB; ++kk)
-                    u[kk] = (okc && kk < nbk) ? ldg(elem(rowmap[k0 + kk], J)) : mk(0.0, 0.0);
-                for (int t = part; t < nrem; t += wpc) {
-                    if (pivof[t] >= 0) continue;  // uniform per wave
-                    const int R = physrow[t];
-                    const double2* lp = panel + t * NB;
-                    if (okc) {
-                        double2* px = elem(R, J);
-                        cd x = ldg(px);
+                for (int r = 0; r < 4; ++r) {
+                    const double2* p = tile_ptr(tile, r);
+                    const double2 x = p ? *p : make_double2(0.0, 0.0);
+                    t.re[r] = x.x, t.im[r] = x.y;
+                }
+            };
+            CTile cur, nxt;
+            if (wave < nrt * nct) fetch(wave, cur);
+            for (int tile = wave; tile < nrt * nct; tile += BW) {
+                const int ct = tile / nrt, rt = tile - ct * nrt;
+                if (ct != cur_ct) {  // wave-uniform
+                    cur_ct = ct;
+                    const int J = J0 + ct * 16 + i16;
 #pragma unroll
-                        for (int kk = 0; kk < NB; ++kk) {
-                            const double2 l = lp[kk];
-                            x = x - mk(l.x, l.y) * u[kk];
-                        }
-                        stg(px, x);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int k = 4 * ks + kq;
+                        const cd u = (J < 2 * n && k < nbk) ? ldg(elem(rowmap[k0 + k], J)) : mk(0.0, 0.0);
+                        ure[ks] = u.x, uim[ks] = u.y;
                     }
                 }
+                fetch(tile + BW, nxt);
+                const int ri = rt * 16 + i16;
+                double nlre[4], lim[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = 4 * ks + kq;
+                    const double2 l = (ri < nrows && k < nbk) ? panel[ri * LS + k] : make_double2(0.0, 0.0);
+                    nlre[ks] = -l.x, lim[ks] = l.y;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    cur.re = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], ure[ks], cur.re, 0, 0, 0);
+                    cur.im = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], uim[ks], cur.im, 0, 0, 0);
+                    cur.re = __builtin_amdgcn_mfma_f64_16x16x4f64(lim[ks], uim[ks], cur.re, 0, 0, 0);
+                    cur.im = __builtin_amdgcn_mfma_f64_16x16x4f64(-lim[ks], ure[ks], cur.im, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double2* p = tile_ptr(tile, r);
+                    if (p) *p = make_double2(cur.re[r], cur.im[r]);
+                }
+                cur = nxt;
             }
         }
         __syncthreads();
@@ -343,7 +389,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
 }  // namespace
 
 size_t trace_solve_blocked_lds(int n) {
-    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)n * NB) * sizeof(double2);
+    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)n * LS) * sizeof(double2);
 }
 
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
