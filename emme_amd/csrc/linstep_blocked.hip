@@ -40,7 +40,6 @@ __device__ __forceinline__ void stg(double2* p, cd v) { *p = make_double2(v.x, v
 struct BlkShared {
     double s_val[BW];
     int s_idx[BW];
-    int piv_thread;   // winner of the current column, -1 = singular
     int info;
     int nrem;
     double tr[2];
@@ -84,6 +83,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         cd pr[NB];
         int myrow = -1;
         int mypiv = -1;
+        bool singular = false;
         if (tid < nrem) {
             myrow = rowmap[k0 + tid];
 #pragma unroll
@@ -109,20 +109,21 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
                 }
                 if (lane == 0) sh.s_val[wave] = best, sh.s_idx[wave] = bidx;
                 __syncthreads();
-                if (tid == 0) {
-                    double bv = sh.s_val[0];
-                    int bi = sh.s_idx[0];
-                    for (int w = 1; w < BW; ++w)
-                        if (sh.s_val[w] > bv || (sh.s_val[w] == bv && sh.s_idx[w] < bi))
-                            bv = sh.s_val[w], bi = sh.s_idx[w];
-                    if (!(bv > 0.0)) {  // exactly singular (or NaN) column
-                        if (sh.info == 0) sh.info = k0 + kk + 1;
-                        bi = -1;
-                    }
-                    sh.piv_thread = bi;
+                // every thread reduces the 16 wave results itself (same answer everywhere):
+                // no second barrier, no serial scan by one thread
+                double bv = sh.s_val[0];
+                int pt = sh.s_idx[0];
+#pragma unroll
+                for (int w = 1; w < BW; ++w) {
+                    const double ov = sh.s_val[w];
+                    const int oi = sh.s_idx[w];
+                    if (ov > bv || (ov == bv && oi < pt)) bv = ov, pt = oi;
                 }
-                __syncthreads();
-                const int pt = sh.piv_thread;
+                if (!(bv > 0.0)) {  // exactly singular (or NaN) column
+                    if (tid == 0 && !singular) sh.info = k0 + kk + 1;
+                    singular = true;
+                    pt = -1;
+                }
                 if (pt >= 0) {
                     if (tid == pt) {
                         mypiv = kk;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
                 }
             }
         }
-        if (sh.info != 0) break;  // uniform (read after the last barrier of the panel)
+        if (singular) break;  // uniform: every thread made the same reduction
 
         // ---- publish the panel: U11 -> global, new row order, multipliers -> LDS -------------
         if (tid < nrem) {
@@ -223,67 +224,70 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
             const int i16 = lane & 15, kq = lane >> 4;
             int cur_ct = -1;
             double ure[4], uim[4];
-            // the C tile of the NEXT trip is fetched before the products of the current one,
-            // so every wave keeps two tiles' worth of loads in flight
-            struct CTile {
-                d4 re, im;
-            };
-            // element (row 4 r + kq of row tile rt, column i16 of column tile ct), or null
-            auto tile_ptr = [&](int tile, int r) -> double2* {
-                const int ct = tile / nrt, rt = tile - ct * nrt;
-                const int J = J0 + ct * 16 + i16;
-                const int rr = rt * 16 + kq + 4 * r;
-                return (tile < nrt * nct && J < 2 * n && rr < nrows) ? elem(rowmap[k0 + nbk + rr], J) : nullptr;
-            };
-            auto fetch = [&](int tile, CTile& t) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2* p = tile_ptr(tile, r);
-                    const double2 x = p ? *p : make_double2(0.0, 0.0);
-                    t.re[r] = x.x, t.im[r] = x.y;
-                }
-            };
-            CTile cur, nxt;
-            if (wave < nrt * nct) fetch(wave, cur);
+            double2* colbase = a;  // &[A | B](row 0, this lane's column)
+            bool okc = false;
+            // Branch-free inner loop: out-of-range rows / columns are clamped to valid
+            // addresses for the loads (their operands are zeroed, their results never stored),
+            // so a tile is 4 LDS index reads, 4 LDS operand reads, 4 loads, 16 MFMAs, 4 stores.
             for (int tile = wave; tile < nrt * nct; tile += BW) {
                 const int ct = tile / nrt, rt = tile - ct * nrt;
                 if (ct != cur_ct) {  // wave-uniform
                     cur_ct = ct;
                     const int J = J0 + ct * 16 + i16;
+                    okc = J < 2 * n;
+                    const int Jc = okc ? J : 2 * n - 1;
+                    colbase = Jc < n ? a + Jc : bb + (Jc - n);
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
                         const int k = 4 * ks + kq;
-                        const cd u = (J < 2 * n && k < nbk) ? ldg(elem(rowmap[k0 + k], J)) : mk(0.0, 0.0);
-                        ure[ks] = u.x, uim[ks] = u.y;
+                        const int kc = k < nbk ? k : nbk - 1;
+                        const double2 u = colbase[(size_t)rowmap[k0 + kc] * n];
+                        const bool ok = okc && k < nbk;
+                        ure[ks] = ok ? u.x : 0.0, uim[ks] = ok ? u.y : 0.0;
                     }
                 }
-                fetch(tile + BW, nxt);
+                // this lane's four C rows (C/D map: row kq + 4 r)
+                double2* px[4];
+                bool okr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = rt * 16 + kq + 4 * r;
+                    okr[r] = okc && rr < nrows;
+                    const int rc = rr < nrows ? rr : nrows - 1;
+                    px[r] = colbase + (size_t)rowmap[k0 + nbk + rc] * n;
+                }
+                d4 cre, cim;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 x = *px[r];
+                    cre[r] = x.x, cim[r] = x.y;
+                }
                 const int ri = rt * 16 + i16;
+                const int ric = ri < nrows ? ri : nrows - 1;
                 double nlre[4], lim[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const int k = 4 * ks + kq;
-                    const double2 l = (ri < nrows && k < nbk) ? panel[ri * LS + k] : make_double2(0.0, 0.0);
-                    nlre[ks] = -l.x, lim[ks] = l.y;
+                    const int k = 4 * ks + kq;  // < NB <= LS: inside the padded LDS row
+                    const double2 l = panel[ric * LS + k];
+                    const bool ok = ri < nrows && k < nbk;
+                    nlre[ks] = ok ? -l.x : 0.0, lim[ks] = ok ? l.y : 0.0;
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    cur.re = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], ure[ks], cur.re, 0, 0, 0);
-                    cur.im = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], uim[ks], cur.im, 0, 0, 0);
-                    cur.re = __builtin_amdgcn_mfma_f64_16x16x4f64(lim[ks], uim[ks], cur.re, 0, 0, 0);
-                    cur.im = __builtin_amdgcn_mfma_f64_16x16x4f64(-lim[ks], ure[ks], cur.im, 0, 0, 0);
+                    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], ure[ks], cre, 0, 0, 0);
+                    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], uim[ks], cim, 0, 0, 0);
+                    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(lim[ks], uim[ks], cre, 0, 0, 0);
+                    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(-lim[ks], ure[ks], cim, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double2* p = tile_ptr(tile, r);
-                    if (p) *p = make_double2(cur.re[r], cur.im[r]);
-                }
-                cur = nxt;
+                for (int r = 0; r < 4; ++r)
+                    if (okr[r]) *px[r] = make_double2(cre[r], cim[r]);
             }
         }
         __syncthreads();
     }
 
+    __syncthreads();  // sh.info (written by thread 0 on a singular column) is visible
     if (sh.info != 0) {
         if (tid == 0) {
             tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
