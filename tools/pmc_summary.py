@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Sum rocprofv3 --pmc counter CSVs per kernel (development tool).
+  python tools/pmc_summary.py <dir with pass*/.../*_counter_collection.csv> <out.json>"""
+import csv, glob, json, os, re, sys
+
+def short(name):
+    m = re.search(r"(k_[a-z_]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+
+root, out = sys.argv[1], sys.argv[2]
+acc, launches = {}, {}
+for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if not k.startswith("k_"):
+            continue
+        acc.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen.add((k, r["Dispatch_Id"]))
+    for k, _ in seen:
+        launches.setdefault(k, {})[f] = launches.setdefault(k, {}).get(f, 0) + 1
+res = {"kernels": {}}
+for k, c in acc.items():
+    n = max(launches[k].values())
+    d = dict(c)
+    d["launches"] = n
+    if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_INSTS_VALU"):
+        d["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"])
+    if c.get("SQ_WAVE_CYCLES"):
+        for nm in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES"):
+            if nm in c:
+                d[nm + "_per_wave_cycle"] = c[nm] / c["SQ_WAVE_CYCLES"]
+    if "TCC_HIT_sum" in c:
+        d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0.0))
+    if "FETCH_SIZE" in c:  # KB (rocprofv3 derived metric), per launch in bytes
+        d["hbm_fetch_bytes_per_launch"] = c["FETCH_SIZE"] * 1024.0 / n
+    if "WRITE_SIZE" in c:
+        d["hbm_write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024.0 / n
+    res["kernels"][k] = d
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: {a: b for a, b in v.items() if not a.startswith("SQ_") or a.endswith("cycle")} for k, v in res["kernels"].items()}, indent=1))
