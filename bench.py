@@ -121,6 +121,20 @@ def cpu_baseline(d, guesses, budget_s=25.0):
             "roots_per_s": roots / dt}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this build
+    (profiles/, separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md); bench.py cannot
+    collect hardware counters itself.  Raw counter figures (no gfx950 x2 read correction)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_pmc_summary.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel]
+        return (k["hbm_fetch_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
+                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v4_pmc_summary.json "
+                "(rocprofv3 --pmc passes over tools/iter_profile.py, same workload)")
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC summary for this kernel under profiles/"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +221,7 @@ def main():
         # the cached kernel; they stream from HBM / Infinity Cache / L2) + dim^2 entries written
         # (16 B M, 16 B M', 16 B read of M_old in the fused secant epilogue)
         bytes_alg = prof.gk_intervals * 15 * 64.0 + prof.matrices * dim * dim * 48.0
+        traffic, traffic_note = pmc_traffic("k_assemble_cached<15>")
         out = {
             "metric": "omega-points solved/sec (256-pt grid)",
             "value": total_points / dt,
@@ -229,11 +244,11 @@ def main():
             "omega_points_per_step": total_points / args.steps,
             "converged_fraction": float(stats[2]) / float(stats[3]),
             "roofline": {
-                "bound": "fp64-valu",
-                "kernel": ctx.fill_kernel() + " (+ k_assemble<.,list> for deferred integrals)",
+                "bound": "fp64-valu",  # neither HBM nor MFMA bounds this path
+                "kernel": ctx.fill_kernel() + " (+ k_assemble_coop for deferred integrals)",
                 "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP64_VECTOR_PEAK_TF,
-                "traffic": None,
+                "traffic": traffic, "traffic_note": traffic_note,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches": prof.assemble_launches,
                 "integrand_evals_per_launch": evals / n_launch,
                 "flop_per_eval_convention": FLOP_PER_EVAL,
@@ -249,7 +264,8 @@ def main():
                 "achieved": bytes_alg / asm_s / 1e9 if asm_s > 0 else 0.0,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (bytes_alg / asm_s / 1e9) / HBM_PEAK_GBS if asm_s > 0 else 0.0,
-                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_alg / n_launch,
+                "traffic": traffic, "traffic_note": traffic_note,
                 "note": "algorithmic bytes = node records consumed + matrix entries written, per second "
                         "of the main fill kernel; most record reads are served by L2 / Infinity Cache "
                         "(measured HBM-side FETCH_SIZE per launch: see profiles/)",
