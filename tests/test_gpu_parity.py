@@ -458,3 +458,42 @@ def test_run_json_qr_method(emme, oracle, tmp_path):
     ev = out["result"]["(None)"]["scan_result"][0]["eigenvalue"]
     w_or, _ = oracle.solve_root_qr(oracle.params(d), complex(*d["initial_guess"]))
     assert abs(complex(ev[0], ev[1]) - w_or) <= 2e-6 * abs(w_or)  # 6 significant digits
+
+
+# ---- maximum sizes: properties that need no oracle run (BASELINE configs[3] and [4]) ----------
+@pytest.mark.parametrize("case", ["es512", "em256"])
+def test_full_size_newton_step_properties(emme, oracle, case):
+    """N=512 electrostatic (dim 512, 130 816 pairs) and N=256 electromagnetic stellarator
+    (dim 512, GK31, three moments): structure of M, secant M', and BOTH Newton steps recomputed
+    on the host from the device's own matrices (numpy solve / the LAPACK QR sequence)."""
+    if case == "es512":
+        d, g = example_tokamak(npoints=512), -0.8 + 0.25j
+    else:
+        d, g = example_stellarator(npoints=256), -1.656 + 2.49j
+    w0, w1 = 0.99 * g, g
+    with _ctx(emme, d) as ctx:
+        n = ctx.dim
+        assert n == 512
+        M01 = ctx.assemble([w0, w1])
+        M0, M1 = M01[0], M01[1]
+        Mp = (M1 - M0) / (w1 - w0)
+        w_tr, dw_tr, Mn, Mpn, info = ctx.newton_step([w1], M1[None], Mp[None], method=0)
+        w_qr, dw_qr, _, _, info_qr = ctx.newton_step([w1], M1[None], Mp[None], method=1)
+        Mchk = ctx.assemble([w_tr[0]])[0]
+    N = n if case == "es512" else n // 2
+    if case == "es512":
+        assert np.array_equal(M1, M1.T)  # both halves of every pair come from one integral
+        assert np.all(M1.diagonal() == M1[0, 0])
+    else:
+        A, B, C, D = M1[:N, :N], M1[:N, N:], M1[N:, :N], M1[N:, N:]
+        assert np.array_equal(A, A.T) and np.array_equal(D, D.T)  # include/solver.h:461-511
+        assert np.array_equal(C, -B) and np.array_equal(B, -B.T)  # B_ij = -B_ji, C = -B
+    assert info[0] == 0 and info_qr[0] == 0
+    want_tr = -1.0 / np.trace(np.linalg.solve(M1, Mp))
+    assert abs(dw_tr[0] - want_tr) <= 1e-9 * abs(want_tr)
+    want_qr, _ = oracle.qr_secant(M1, Mp)
+    assert abs(dw_qr[0] - want_qr) <= 1e-9 * abs(want_qr)
+    # the step's own output matrices: M(new omega) and the new secant
+    scale = np.abs(Mchk).max()
+    assert np.abs(Mn[0] - Mchk).max() <= 1e-12 * scale
+    assert np.abs(Mpn[0] - (Mn[0] - M1) / dw_tr[0]).max() <= 1e-9 * np.abs(Mpn[0]).max()
