@@ -70,10 +70,11 @@ __device__ __forceinline__ GkLane gk_lane(int r) {
     return g;
 }
 
+// all-reduce over a lane group of 16 (one DPP row) or 32 (two rows) lanes
 template <int GW>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int off = 1; off < GW; off <<= 1) v += __shfl_xor(v, off, GW);
+    v = row16_sum(v);
+    if (GW == 32) v += __shfl_xor(v, 16);
     return v;
 }
 

@@ -67,12 +67,6 @@ struct emme_ctx {
     unsigned long long* d_rounds = nullptr;  // diagnostic counter of the omega-lane kernel
     int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
     int* d_chunks = nullptr;   // (first, size) of every omega chunk of the cached kernel
-    int* d_longmask = nullptr; // batch items routed to the lanes-are-nodes kernel (long integrals)
-    std::vector<int> h_longmask;
-    hipStream_t stream2 = nullptr;  // the two fill kernels of one assembly run side by side
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    double long_threshold = 1e30;  // off by default (no gain measured on the bench workload)
-    // // mean GK intervals per integral above which an omega is "long"
     std::vector<int> h_chunks;
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
     int last_fill_mode = -1;   // kernel family of the last fill: 0 nodes, 1 omega-lane, 2 cached
@@ -172,7 +166,7 @@ int ensure_batch(emme_ctx* c, int nb) {
         p = nullptr;
     };
     F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active), F(c->d_iters), F(c->d_info),
-        F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks), F(c->d_longmask);
+        F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks);
     c->cap = 0;
     HIP_TRY(hipMalloc((void**)&c->d_omega, sizeof(double) * 2 * nb));
     HIP_TRY(hipMalloc((void**)&c->d_domega, sizeof(double) * 2 * nb));
@@ -184,7 +178,6 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(hipMalloc((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_actidx, sizeof(int) * nb));
     HIP_TRY(hipMalloc((void**)&c->d_chunks, sizeof(int) * 2 * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_longmask, sizeof(int) * nb));
     if (!c->d_rounds) {
         HIP_TRY(hipMalloc((void**)&c->d_rounds, sizeof(unsigned long long)));
         HIP_TRY(hipMemset(c->d_rounds, 0, sizeof(unsigned long long)));
@@ -446,25 +439,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     }
     if (use_cache) {
         const int gw = L.gk_points == 15 ? 16 : 32;
-        // Omegas whose integrals are very long (hundreds of intervals each: strongly damped
-        // points) are latency-bound on a single lane.  They go to the lanes-are-nodes kernel,
-        // which advances all nodes of an interval in parallel and also reads the node cache;
-        // it runs next to the cached kernel on a second stream.
-        std::vector<int>& lm = c->h_longmask;
-        lm.assign(nbatch, 0);
-        int n_long = 0;
-        if (cost) {
-            const double per_integral = (double)c->npairs * c->nm;
-            std::vector<int> keep;
-            for (int b : idx) {
-                if ((double)cost[b] > c->long_threshold * per_integral)
-                    lm[b] = 1, ++n_long;
-                else
-                    keep.push_back(b);
-            }
-            idx.swap(keep);
-        }
-        // Omega chunks of unequal size for the rest.  Every lane walks ONE omega's trees, so an
+        // Omega chunks of unequal size.  Every lane walks ONE omega's trees, so an
         // omega whose integrals need 3x the intervals keeps its lane busy 3x longer than its
         // neighbours'.  A chunk of n omegas gives each of them gw/n lanes per group: expensive
         // omegas go into small chunks, cheap ones share a chunk 16 (32) at a time.  idx is
@@ -494,25 +469,6 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
         c->last_fill_mode = 2;
-        if (n_long) {
-            // fork: the long-integral omegas on stream2, concurrently with the cached kernel
-            if (!c->stream2) {
-                HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-            }
-            HIP_TRY(hipMemcpyAsync(c->d_longmask, lm.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            AssembleLaunch L2 = L;
-            L2.active = c->d_longmask;
-            L2.items_per_group = items_per_group_for(c, n_long);
-            {
-                ScopedSpan s2(c, K_DEFER, c->stream2, true);
-                HIP_TRY(launch_assemble(L2, c->stream2, &c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab));
-            }
-            HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
-        }
         if (n_lane) {
             ScopedSpan s(c, K_ASM);
             HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale,
@@ -524,7 +480,6 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
                                          c->d_recs_ext, c->d_ttab, c->stream));
         }
-        if (n_long) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
             (void)hipMemcpy(&cnt, c->d_worklist_count, sizeof cnt, hipMemcpyDeviceToHost);
@@ -595,7 +550,6 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->device = device;
     if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
     if (const char* e = std::getenv("EMME_NODE_CACHE_GB")) c->cache_budget_gb = std::atof(e);
-    if (const char* e = std::getenv("EMME_LONG_THRESHOLD")) c->long_threshold = std::atof(e);
     const int N = p->npoints;
     c->N = N;
     const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
@@ -657,7 +611,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         if (p) (void)hipFree((void*)p);
     };
     F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
-        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_chunks), F(c->d_longmask), F(c->d_M),
+        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_chunks), F(c->d_M),
         F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (int k = 0; k < 2; ++k) {
@@ -666,9 +620,6 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     }
     F(c->d_scale);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     delete c;

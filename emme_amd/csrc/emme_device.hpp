@@ -38,6 +38,39 @@ __device__ __forceinline__ cd conj(cd a) { return cd{a.x, -a.y}; }
 // multiply by i
 __device__ __forceinline__ cd times_i(cd a) { return cd{-a.y, a.x}; }
 
+// ---- cross-lane sums without LDS traffic (DPP) ------------------------------------------
+// One step: v + (v of the lane selected by the DPP control).  Controls used: quad_perm
+// [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140:
+// after the four of them every lane of a 16-lane row holds the row's sum, and because
+// floating-point addition is commutative every lane holds the SAME bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_step(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v = dpp_add_step<0xB1>(v);
+    v = dpp_add_step<0x4E>(v);
+    v = dpp_add_step<0x141>(v);
+    v = dpp_add_step<0x140>(v);
+    return v;
+}
+// sum over all 64 lanes, in every lane (rows combined in a fixed order)
+__device__ __forceinline__ double wave64_sum(double v) {
+    v = row16_sum(v);
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 16 * r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16 * r);
+        s += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return s;
+}
+
 // 1/x and 1/sqrt(x) for normal-range arguments: hardware seed (v_rcp_f64 / v_rsq_f64) +
 // two Newton steps, i.e. the compiler's own division sequence without the range scaling
 // and fix-up instructions that exist for subnormal/overflow operands (never met here).

@@ -28,6 +28,7 @@ namespace {
 constexpr int BT = 1024;     // threads per workgroup
 constexpr int BW = BT / 64;  // waves
 constexpr int NB = 16;
+static_assert(BW == 16, "the cross-wave pivot reduction reads one candidate per lane of a 16-lane row");
 constexpr int LS = NB + 1;  // row stride of the L21 panel in LDS (double2 units)
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -37,7 +38,39 @@ __device__ __forceinline__ cd ldg(const double2* p) {
 }
 __device__ __forceinline__ void stg(double2* p, cd v) { *p = make_double2(v.x, v.y); }
 
+// max over the 16 lanes of a DPP row, result in every lane of the row (no LDS traffic):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long row16_max(unsigned long long v) {
+    v = dpp_max_step<0xB1>(v);
+    v = dpp_max_step<0x4E>(v);
+    v = dpp_max_step<0x141>(v);
+    v = dpp_max_step<0x140>(v);
+    return v;
+}
+// max over the whole wave, in every lane
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
+    v = row16_max(v);
+    unsigned long long m = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * r);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        m = o > m ? o : m;
+    }
+    return m;
+}
+
 struct BlkShared {
+    unsigned long long s_key[BW];  // per-wave pivot candidates
     double s_val[BW];
     int s_idx[BW];
     int info;
@@ -93,32 +126,21 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) {
             if (kk < nbk) {  // uniform
-                // pivot search: max modulus among rows not yet used in this block;
-                // ties go to the smallest logical position (first maximum)
-                double best = -1.0;
-                int bidx = BT;
-                if (tid < nrem && mypiv < 0) {
-                    best = norm2(pr[kk]);
-                    bidx = tid;
-                }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const double ov = __shfl_xor(best, off);
-                    const int oi = __shfl_xor(bidx, off);
-                    if (ov > best || (ov == best && oi < bidx)) best = ov, bidx = oi;
-                }
-                if (lane == 0) sh.s_val[wave] = best, sh.s_idx[wave] = bidx;
+                // pivot search: max modulus among rows not yet used in this block.  Candidates
+                // are 64-bit keys: the modulus' bit pattern (non-negative doubles order like
+                // integers) with its 10 lowest bits replaced by 1023 - slot, so that a plain
+                // integer maximum picks the largest modulus (to 2^-42) and, among equals, the
+                // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
+                unsigned long long key = 0;
+                if (tid < nrem && mypiv < 0)
+                    key = ((unsigned long long)__double_as_longlong(norm2(pr[kk])) & ~1023ull) |
+                          (unsigned long long)(1023 - tid);
+                key = wave_max(key);
+                if (lane == 0) sh.s_key[wave] = key;
                 __syncthreads();
-                // every thread reduces the 16 wave results itself (same answer everywhere):
-                // no second barrier, no serial scan by one thread
-                double bv = sh.s_val[0];
-                int pt = sh.s_idx[0];
-#pragma unroll
-                for (int w = 1; w < BW; ++w) {
-                    const double ov = sh.s_val[w];
-                    const int oi = sh.s_idx[w];
-                    if (ov > bv || (ov == bv && oi < pt)) bv = ov, pt = oi;
-                }
+                key = row16_max(sh.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
+                int pt = 1023 - (int)(key & 1023ull);
+                const double bv = __longlong_as_double((long long)(key & ~1023ull));
                 if (!(bv > 0.0)) {  // exactly singular (or NaN) column
                     if (tid == 0 && !singular) sh.info = k0 + kk + 1;
                     singular = true;

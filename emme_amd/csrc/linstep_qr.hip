@@ -41,11 +41,7 @@ __device__ __forceinline__ cd ldq(const double2* p) {
 }
 __device__ __forceinline__ void stq(double2* p, cd v) { *p = make_double2(v.x, v.y); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave64_sum(v); }
 
 // plain complex quotient (Smith-free textbook form is what the BLAS kernels use)
 __device__ __forceinline__ cd cquot(cd a, cd b) {
