@@ -6,16 +6,16 @@
 //            owner thread; partial pivoting = block argmax per column, the winner publishes
 //            its row through LDS; no row is ever moved in memory (a row map keeps the pivot
 //            order).  Multipliers never go to global memory.
-//   trailing each lane owns one column J of the augmented matrix [A | B]: it loads the NB
-//            pivot-row entries of that column, finishes them with the NB x NB unit-lower
-//            block (forward substitution in registers), stores them (they are rows of U /
-//            of L^-1 P B) and then streams every remaining row once:
-//                x <- x - sum_k L21[row][k] * u[k]        (L21 broadcast from LDS)
-//            i.e. the trailing matrix is read and written once per NB columns instead of
-//            once per column: 16x less L2/Infinity-Cache traffic than the unblocked kernel.
+//   trailing T1: each lane owns one column J of the augmented matrix [A | B], loads the NB
+//            pivot-row entries of that column, finishes them with the NB x NB unit-lower block
+//            (forward substitution in registers) and stores them: rows of U / of L^-1 P B.
+//            T2: the rows below the block, X -= L21 * U12, as 16 x 16 complex tiles on the
+//            FP64 matrix cores (mfma_update below; L21 in LDS in pivot order): the trailing
+//            matrix is read and written once per NB columns.
 //   back     the truncated back substitution (X(c,c) needs rows c..n-1 of column c only) in
 //            the same shape: per block of NB rows a register triangular solve per column,
-//            then one streamed update of the rows above with the U column block in LDS.
+//            then the rows above are updated by the same MFMA tile routine with the U column
+//            block in LDS (tiles right of the diagonal are skipped).
 #include <hip/hip_runtime.h>
 
 #include "emme_device.hpp"
@@ -77,6 +77,88 @@ struct BlkShared {
     int nrem;
     double tr[2];
 };
+
+// C(rows, cols) -= A(rows, 0:nbk) * B(0:nbk, cols) for complex matrices on the FP64 matrix cores:
+// one 16 x 16 tile per wave and trip, v_mfma_f64_16x16x4_f64, four k-steps, and per k-step four
+// products for the complex multiply-subtract
+//     Cre += (-Are) Bre + Aim Bim,   Cim += (-Are) Bim + (-Aim) Bre.
+// Operand maps (one f64 per lane): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15];
+// C/D: column lane & 15, row (lane >> 4) + 4 r.
+//   C rows : logical rows crow0 .. crow0 + nrows - 1 (physical row = rowmap[.])
+//   A      : LDS `panel`, row (logical row - crow0), rows LS entries apart
+//   B rows : logical rows brow0 .. brow0 + nbk - 1, read from memory once per column tile
+//   cols   : columns col0 .. col0 + ncols - 1 of the augmented matrix [a | bb]
+//   LOWER  : only tiles that contain an entry with (row - crow0) >= (col - col0) are touched
+// The inner loop is branch-free: out-of-range rows / columns are clamped to valid addresses for
+// the loads (their operands are zeroed, their results never stored), so a tile is 4 LDS index
+// reads, 4 LDS operand reads, 4 loads, 16 MFMAs, 4 stores.
+template <bool LOWER>
+__device__ __forceinline__ void mfma_update(int n, double2* a, double2* bb, const int* rowmap,
+                                            const double2* panel, int crow0, int nrows, int brow0,
+                                            int nbk, int col0, int ncols, int wave, int lane) {
+    const int nrt = (nrows + 15) >> 4, nct = (ncols + 15) >> 4;
+    const int i16 = lane & 15, kq = lane >> 4;
+    int cur_ct = -1;
+    double bre[4], bim[4];
+    double2* colbase = a;  // &[a | bb](row 0, this lane's column)
+    bool okc = false;
+    for (int tile = wave; tile < nrt * nct; tile += BW) {
+        const int ct = tile / nrt, rt = tile - ct * nrt;
+        if (LOWER && ct > rt) continue;  // wave-uniform
+        if (ct != cur_ct) {              // wave-uniform
+            cur_ct = ct;
+            const int J = col0 + ct * 16 + i16;
+            okc = J < col0 + ncols;
+            const int Jc = okc ? J : col0 + ncols - 1;
+            colbase = Jc < n ? a + Jc : bb + (Jc - n);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + kq;
+                const int kc = k < nbk ? k : nbk - 1;
+                const double2 u = colbase[(size_t)rowmap[brow0 + kc] * n];
+                const bool ok = okc && k < nbk;
+                bre[ks] = ok ? u.x : 0.0, bim[ks] = ok ? u.y : 0.0;
+            }
+        }
+        // this lane's four C rows (C/D map: row kq + 4 r)
+        double2* px[4];
+        bool okr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = rt * 16 + kq + 4 * r;
+            okr[r] = okc && rr < nrows;
+            const int rc = rr < nrows ? rr : nrows - 1;
+            px[r] = colbase + (size_t)rowmap[crow0 + rc] * n;
+        }
+        d4 cre, cim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 x = *px[r];
+            cre[r] = x.x, cim[r] = x.y;
+        }
+        const int ri = rt * 16 + i16;
+        const int ric = ri < nrows ? ri : nrows - 1;
+        double nare[4], aim[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + kq;  // < NB <= LS: inside the padded LDS row
+            const double2 l = panel[ric * LS + k];
+            const bool ok = ri < nrows && k < nbk;
+            nare[ks] = ok ? -l.x : 0.0, aim[ks] = ok ? l.y : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nare[ks], bre[ks], cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nare[ks], bim[ks], cim, 0, 0, 0);
+            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[ks], bim[ks], cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[ks], bre[ks], cim, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (okr[r]) *px[r] = make_double2(cre[r], cim[r]);
+    }
+}
+
 
 __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, double2* B,
                                                             const int* active, double2* tr_out,
@@ -233,79 +315,8 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
             }
         }
         __syncthreads();
-        // T2: X(rows below the block, trailing columns) -= L21 * U12 on the matrix cores, one
-        //     16 x 16 tile per wave and trip: v_mfma_f64_16x16x4_f64, four k-steps, and per
-        //     k-step four products for the complex multiply-subtract
-        //         Xre += (-Lre) Ure + Lim Uim,   Xim += (-Lre) Uim + (-Lim) Ure.
-        //     Operand maps (one f64 per lane): A[i = lane & 15][k = lane >> 4],
-        //     B[k = lane >> 4][j = lane & 15]; C/D: column lane & 15, row (lane >> 4) + 4 r.
-        //     A tile's 16 x 16 B operand (U12) stays in registers across the row tiles.
-        {
-            const int nrows = nrem - nbk;
-            const int nrt = (nrows + 15) >> 4, nct = (ncols + 15) >> 4;
-            const int i16 = lane & 15, kq = lane >> 4;
-            int cur_ct = -1;
-            double ure[4], uim[4];
-            double2* colbase = a;  // &[A | B](row 0, this lane's column)
-            bool okc = false;
-            // Branch-free inner loop: out-of-range rows / columns are clamped to valid
-            // addresses for the loads (their operands are zeroed, their results never stored),
-            // so a tile is 4 LDS index reads, 4 LDS operand reads, 4 loads, 16 MFMAs, 4 stores.
-            for (int tile = wave; tile < nrt * nct; tile += BW) {
-                const int ct = tile / nrt, rt = tile - ct * nrt;
-                if (ct != cur_ct) {  // wave-uniform
-                    cur_ct = ct;
-                    const int J = J0 + ct * 16 + i16;
-                    okc = J < 2 * n;
-                    const int Jc = okc ? J : 2 * n - 1;
-                    colbase = Jc < n ? a + Jc : bb + (Jc - n);
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int k = 4 * ks + kq;
-                        const int kc = k < nbk ? k : nbk - 1;
-                        const double2 u = colbase[(size_t)rowmap[k0 + kc] * n];
-                        const bool ok = okc && k < nbk;
-                        ure[ks] = ok ? u.x : 0.0, uim[ks] = ok ? u.y : 0.0;
-                    }
-                }
-                // this lane's four C rows (C/D map: row kq + 4 r)
-                double2* px[4];
-                bool okr[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = rt * 16 + kq + 4 * r;
-                    okr[r] = okc && rr < nrows;
-                    const int rc = rr < nrows ? rr : nrows - 1;
-                    px[r] = colbase + (size_t)rowmap[k0 + nbk + rc] * n;
-                }
-                d4 cre, cim;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2 x = *px[r];
-                    cre[r] = x.x, cim[r] = x.y;
-                }
-                const int ri = rt * 16 + i16;
-                const int ric = ri < nrows ? ri : nrows - 1;
-                double nlre[4], lim[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int k = 4 * ks + kq;  // < NB <= LS: inside the padded LDS row
-                    const double2 l = panel[ric * LS + k];
-                    const bool ok = ri < nrows && k < nbk;
-                    nlre[ks] = ok ? -l.x : 0.0, lim[ks] = ok ? l.y : 0.0;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], ure[ks], cre, 0, 0, 0);
-                    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nlre[ks], uim[ks], cim, 0, 0, 0);
-                    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(lim[ks], uim[ks], cre, 0, 0, 0);
-                    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(-lim[ks], ure[ks], cim, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (okr[r]) *px[r] = make_double2(cre[r], cim[r]);
-            }
-        }
+        // T2: X(rows below the block, trailing columns) -= L21 * U12 on the matrix cores
+        mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, J0, ncols, wave, lane);
         __syncthreads();
     }
 
@@ -339,14 +350,12 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         }
         for (int e = tid; e < k0 * NB; e += BT) {
             const int rr = e / NB, c = e % NB;
-            panel[e] = c < nbk ? *(&a[(size_t)rowmap[rr] * n + k0 + c]) : make_double2(0.0, 0.0);
+            panel[rr * LS + c] = c < nbk ? *(&a[(size_t)rowmap[rr] * n + k0 + c]) : make_double2(0.0, 0.0);
         }
         __syncthreads();
         const int ncols = k0 + nbk;  // columns 0 .. k1-1 of C are still needed
         const int nchunks = (ncols + 63) / 64;
-        const int wpc = nchunks >= BW ? 1 : BW / nchunks;
-        for (int q = wave / wpc; q < nchunks; q += (nchunks >= BW ? BW : BW / wpc)) {
-            const int part = wave % wpc;
+        for (int q = wave; q < nchunks; q += BW) {
             const int c = q * 64 + lane;
             const bool okc = c < ncols;
             cd x[NB];
@@ -369,25 +378,20 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
                     const double2 rd = L11[kk * NB + kk];
                     s = s * mk(rd.x, rd.y);
                     x[kk] = (k0 + kk >= c) ? s : mk(0.0, 0.0);
-                    if (part == 0 && okc && k0 + kk == c) my_tr = my_tr + s;
+                    if (okc && k0 + kk == c) my_tr = my_tr + s;
                 }
             }
-            // rows above the block: C(rr, c) -= sum_k U(rr, k0+k) x[k], needed for rr >= c
-            const int rr_lo = q * 64;  // rows above the chunk's first column are never used
-            for (int rr = rr_lo + part; rr < k0; rr += wpc) {
-                if (okc && rr >= c) {
-                    double2* px = &bb[(size_t)rowmap[rr] * n + c];
-                    cd v = ldg(px);
-                    const double2* up = panel + rr * NB;
+            // the solved block replaces C's block rows: it is the B operand of the update below
+            if (okc) {
 #pragma unroll
-                    for (int kk = 0; kk < NB; ++kk) {
-                        const double2 uv = up[kk];
-                        v = v - mk(uv.x, uv.y) * x[kk];
-                    }
-                    stg(px, v);
-                }
+                for (int kk = 0; kk < NB; ++kk)
+                    if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
             }
         }
+        __syncthreads();
+        // rows above the block: C(rr, c) -= sum_k U(rr, k0+k) X(k0+k, c), needed for rr >= c only
+        // (column tiles right of the row tile are skipped)
+        mfma_update<true>(n, a, bb, rowmap, panel, 0, k0, k0, nbk, n, ncols, wave, lane);
         __syncthreads();
     }
     // trace = sum of the per-lane diagonal pieces
