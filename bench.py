@@ -125,11 +125,11 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this build
     (profiles/, separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md); bench.py cannot
     collect hardware counters itself.  Raw counter figures (no gfx950 x2 read correction)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_pmc_summary.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v5_pmc_summary.json")
     try:
         k = json.load(open(path))["kernels"][kernel]
         return (k["hbm_fetch_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
-                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v4_pmc_summary.json "
+                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v5_pmc_summary.json "
                 "(rocprofv3 --pmc passes over tools/iter_profile.py, same workload)")
     except (OSError, KeyError, ValueError):
         return None, "no PMC summary for this kernel under profiles/"
