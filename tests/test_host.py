@@ -164,3 +164,18 @@ def test_scan_generator_sequence(emme):
     assert np.allclose(v, [0.02])
     v, t = emme.scan_values(1.0, 0.25, 0.5)  # scalar tail: other tail = head + step/2 -> unused
     assert np.allclose(v, [1.0, 0.75, 0.5])
+
+
+def test_host_layer_under_address_and_ub_sanitizers():
+    """The host C++ layer (JSON dialect, parameters, tables, scan generator, null vector, driver
+    error paths) compiled without the device code and run under ASan + UBSan
+    (emme_amd/csrc/host_selftest.cpp; GPU sanitizers are not available on the target pool)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "emme_amd", "csrc"), "host-sanitize"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host self-test ok" in r.stdout
