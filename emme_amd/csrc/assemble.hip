@@ -45,6 +45,9 @@ struct AsmArgs {
     const NodeRec* recs[2];
     const NodeRec* recs_ext[2][NODE_CACHE_MAX_SUB - 1];
     const double2* ttab[2];
+    // electromagnetic fills with a shared cache: records are those of moment 0, indexed by pair;
+    // moment m multiplies them by (c_nv W)^m with W from wtab (null = one record per moment)
+    const double2* wtab[2];
 };
 
 // Value of the integrand at one quadrature node when a node-record cache may hold the
@@ -62,15 +65,24 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
     const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? A.recs[cls] : A.recs_ext[cls][which]);
     NodeData d;
     if (buf) {
+        const bool shared = A.wtab[cls] != nullptr;
+        const long ci = shared ? cache_item / A.P.nm : cache_item;
         const NodeRec rec =
-            which < 0 ? buf[(cache_item * A.geom.ni_main() + cslot) * GW + lane_in_group]
-                      : buf[(cache_item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
+            which < 0 ? buf[(ci * A.geom.ni_main() + cslot) * GW + lane_in_group]
+                      : buf[(ci * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
                             lane_in_group];
         const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
         d.A0 = mk(rec.A0.x, rec.A0.y);
         d.T = mk(tt.x, tt.y);
         d.Q1 = mk(rec.Q1.x, rec.Q1.y);
         d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+        if (shared && m > 0) {
+            const double2 ww = A.wtab[cls][(long)cslot * GW + lane_in_group];
+            cd nv = pc.c_nv * mk(ww.x, ww.y);
+            if (m == 2) nv = nv * nv;
+            d.Q1 = d.Q1 * nv;
+            d.Q0 = d.Q0 * nv;
+        }
     } else {
         d = node_data(x, A.P, pc, oc.omi, m);
     }
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256) void k_assemble_coop(AsmArgs A) {
 hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const NodeCacheGeom* g,
                            const void* const recs[2],
                            const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
-                           const void* const ttab[2]) {
+                           const void* const ttab[2], const void* const wtab[2]) {
     AsmArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -487,6 +499,7 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const No
     for (int c = 0; c < 2; ++c) {
         A.recs[c] = g ? (const NodeRec*)recs[c] : nullptr;
         A.ttab[c] = g ? (const double2*)ttab[c] : nullptr;
+        A.wtab[c] = (g && wtab) ? (const double2*)wtab[c] : nullptr;
         for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k)
             A.recs_ext[c][k] = g ? (const NodeRec*)recs_ext[c][k] : nullptr;
     }
@@ -516,7 +529,8 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const unsigned int* count, const NodeCacheGeom* g,
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
-                                const void* const ttab[2], hipStream_t stream) {
+                                const void* const ttab[2], const void* const wtab[2],
+                                hipStream_t stream) {
     AsmArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -536,6 +550,7 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     for (int c = 0; c < 2; ++c) {
         A.recs[c] = g ? (const NodeRec*)recs[c] : nullptr;
         A.ttab[c] = g ? (const double2*)ttab[c] : nullptr;
+        A.wtab[c] = (g && wtab) ? (const double2*)wtab[c] : nullptr;
         for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k)
             A.recs_ext[c][k] = g ? (const NodeRec*)recs_ext[c][k] : nullptr;
     }

@@ -51,6 +51,7 @@ struct CacheArgs {
     double omi;      // class being built
     NodeRec* recs;   // [nitems][count][GW]: the cached intervals first .. first+count-1
     double2* ttab;   // [NI][GW]  T per (interval, node), all regions
+    double2* wtab;   // null, or [NI][GW] moment factor W: records are per PAIR (moment 0)
     double* scale;   // [NI] half-width (r - l)/2 of every cached interval
     int part;          // -1: main buffer (full tree + subtree 0); k >= 0: subtree k+1
     int first, count;  // global slot of the first interval and number of intervals filled
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
     const int N = P.N;
     const int NI = A.count;  // intervals per item filled by this launch
     const int lane = threadIdx.x % GW;
-    const long nitems = (long)A.npairs * P.nm;
+    const int nm_items = A.wtab ? 1 : P.nm;  // shared layout: one item per pair
+    const long nitems = (long)A.npairs * nm_items;
     const long total = nitems * NI;
     const GkLane gk = gk_lane<PTS>(lane);
     const double* eta = A.tab;
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
          w += (long)gridDim.x * GROUPS_PER_BLOCK) {
         const long item = w / NI;
         const int idx = (int)(w - item * NI);
-        const int p = (int)(item / P.nm);
-        const int m = (int)(item - (long)p * P.nm);
+        const int p = (int)(item / nm_items);
+        const int m = (int)(item - (long)p * nm_items);
         const ushort2 ij = A.pairs[p];
         const int i = ij.x, j = ij.y;
         const PairConst pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], gtab[i] - gtab[j]);
@@ -94,6 +96,10 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
         A.recs[w * GW + lane] = rec;
         if (item == 0) {
             A.ttab[(long)(A.first + idx) * GW + lane] = make_double2(d.T.x, d.T.y);
+            if (A.wtab) {
+                const cd w = node_w(x, P, A.omi);
+                A.wtab[(long)(A.first + idx) * GW + lane] = make_double2(w.x, w.y);
+            }
             if (lane == 0) A.scale[A.first + idx] = scale;
         }
     }
@@ -108,6 +114,7 @@ struct AsmCachedArgs {
     const NodeRec* recs[2];   // main part per contour class (omi = +1, -1); null if not built
     const NodeRec* recs_ext[2][NODE_CACHE_MAX_SUB - 1];  // run-time subtrees; null if absent
     const double2* ttab[2];   // [NI][GW] per class
+    const double2* wtab[2];   // [NI][GW] per class: moment factor W (shared EM layout only)
     const double* scale;      // [NI]
     unsigned long long* worklist;   // deferred integrals: batch << 32 | item
     unsigned long long* defer_info; // depth << 56 | path of the interval each entry was missing
@@ -335,6 +342,248 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
     }
 }
 
+// ---- electromagnetic fill on the shared cache layout ---------------------------------------------
+// The three integrals of a pair (moments m = 0, 1, 2: blocks A, B, D of the matrix,
+// include/solver.h:461-511) differ only by the factor norm_vel^m = (c_nv W)^m in the integrand, and
+// their adaptive trees are nearly the same.  A lane therefore walks the UNION of the three trees
+// of its (pair, omega): per node one record, one complex exponential, then f1 = f0 nv, f2 = f1 nv;
+// each moment keeps its own Kronrod/Gauss sums, its own abs_tol and its own accept/split decisions
+// (the reference's, moment by moment), and is evaluated exactly on the intervals of its own tree.
+// The walk order is the pre-order of the union: every moment holds the key of the next interval
+// it needs, key = position of the left end (path << (56 - depth)) * 64 + depth, and the lane
+// always takes the smallest key.  ~2.9x fewer intervals and record loads than three separate walks.
+template <int PTS>
+__global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) {
+    constexpr int GW = PTS == 15 ? 16 : 32;
+    constexpr int H = (PTS + 1) / 2;
+    constexpr int GROUPS_PER_BLOCK = 256 / GW;
+    constexpr int KD = 56;  // key layout: depth <= KD
+    extern __shared__ double lds_raw[];  // eta | g | b | scale table
+
+    const DevParams& P = A.P;
+    const int N = P.N, dim = P.dim;
+    for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_raw[k] = A.tab[k];
+    const int NI = A.geom.ni();
+    for (int k = threadIdx.x; k < NI; k += blockDim.x) lds_raw[3 * N + k] = A.scale[k];
+    __syncthreads();
+    const double* eta = lds_raw;
+    const double* gtab = lds_raw + N;
+    const double* btab = lds_raw + 2 * N;
+    const double* scale_tab = lds_raw + 3 * N;
+    const int group_in_block = threadIdx.x / GW;
+    const int lane = threadIdx.x % GW;
+
+    const int2 chunk = A.chunks[blockIdx.y];
+    const int n_in_chunk = chunk.y;
+    int n_eff = 1;
+    while (n_eff < n_in_chunk) n_eff <<= 1;
+    const int nsub = GW / n_eff;
+    const int wslot = lane % n_eff, sub = lane / n_eff;
+    const bool has_w = wslot < n_in_chunk;
+    const int b = has_w ? A.act_idx[chunk.x + wslot] : 0;
+    cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
+    if (has_w) {
+        omega = mk(A.omega[b].x, A.omega[b].y);
+        if (A.Mold) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
+    }
+    const int cls = -copysign(1.0, omega.x) > 0.0 ? 0 : 1;
+    const NodeRec* recs = A.recs[cls];
+    const double2* ttab = A.ttab[cls];
+    const double2* wtab = A.wtab[cls];
+    const int NI_MAIN = A.geom.ni_main();
+    double2* Mb = A.M + (size_t)b * dim * dim;
+    const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
+    double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
+    auto store = [&](int r, int c, cd v) {
+        const size_t idx = (size_t)r * dim + c;
+        Mb[idx] = make_double2(v.x, v.y);
+        if (Moldb) {
+            const double2 o = Moldb[idx];
+            const cd d = (v - mk(o.x, o.y)) * rdw;
+            Mpb[idx] = make_double2(d.x, d.y);
+        }
+    };
+    if (blockIdx.x == 0 && has_w && sub == 0) {  // diagonal (include/solver.h:465-470)
+        for (int i = group_in_block; i < N; i += GROUPS_PER_BLOCK) {
+            store(i, i, mk(P.diag_a, 0.0));
+            store(i, i + N, mk(0.0, 0.0));
+            store(i + N, i, mk(0.0, 0.0));
+            store(i + N, i + N, mk(P.diag_d * btab[i], 0.0));
+        }
+    }
+
+    const double* WK = PTS == 15 ? kWk15 : kWk31;
+    const double* WG = PTS == 15 ? kWg15 : kWg31;
+    const double inv_scale = 2. / (M_PI / 2.0);
+    const int nitems = A.npairs;  // an item is a pair: its three moments travel together
+    const int worker = (blockIdx.x * GROUPS_PER_BLOCK + group_in_block) * nsub + sub;
+    const int nworkers = gridDim.x * GROUPS_PER_BLOCK * nsub;
+    auto make_key = [](int depth, unsigned long long path) -> unsigned long long {
+        return ((path << (KD - depth)) << 6) | (unsigned long long)depth;
+    };
+    const unsigned long long DONE = ~0ull;
+
+    unsigned long long my_intervals = 0;
+    int bad = 0;
+    for (int item = worker; __ballot(has_w && item < nitems) != 0ull; item += nworkers) {
+        const bool mine = has_w && item < nitems;
+        int i = 0, j = 0;
+        double c_nv = 0.0;
+        if (mine) {
+            const ushort2 ij = A.pairs[item];
+            i = ij.x, j = ij.y;
+            c_nv = (P.qR * (eta[i] - eta[j])) / P.vt;  // as make_pair_const
+        }
+        unsigned long long key[3];
+        double abs_tol[3];
+        cd sum[3];
+        int count[3];
+        bool deferred[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            key[m] = mine ? 0ull : DONE;  // root: depth 0, path 0
+            abs_tol[m] = 0.0, sum[m] = mk(0.0, 0.0), count[m] = 0, deferred[m] = false;
+        }
+
+        for (;;) {
+            unsigned long long cur = key[0] < key[1] ? key[0] : key[1];
+            cur = key[2] < cur ? key[2] : cur;
+            if (cur == DONE) break;
+            const int depth = (int)(cur & 63ull);
+            const unsigned long long path = (cur >> 6) >> (KD - depth);
+            int which;
+            const int cslot = A.geom.slot(depth, path, which);
+            const NodeRec* ebuf = which >= 0 ? A.recs_ext[cls][which] : recs;
+            if (cslot < 0 || ebuf == nullptr) {
+                // outside the cache: the moments that need this interval go, whole, to the
+                // cooperative kernel; the others carry on
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    if (key[m] == cur) {
+                        const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+                        A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)(item * 3 + m);
+                        A.defer_info[slot] = ((unsigned long long)depth << 56) | (path & 0xffffffffffffffull);
+                        deferred[m] = true;
+                        key[m] = DONE;
+                    }
+                }
+                continue;
+            }
+            const double scale = scale_tab[cslot];
+            const long off = (long)cslot * GW;
+            const NodeRec* rp =
+                which < 0 ? recs + ((long)item * NI_MAIN + cslot) * GW
+                          : ebuf + ((long)item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW;
+            const double2* tp = ttab + off;
+            const double2* wp = wtab + off;
+            cd K[3], G[3], fplus[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) K[m] = G[m] = fplus[m] = mk(0.0, 0.0);
+            // visiting order s = 0..PTS-1: centre, +x_1, -x_1, +x_2, -x_2, ... (the reference's
+            // summation order, include/functions.h:186-201)
+            auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
+            auto proc = [&](const NodeRec& rec, const double2 tt, const double2 ww, int s) {
+                NodeData d;
+                d.A0 = mk(rec.A0.x, rec.A0.y);
+                d.T = mk(tt.x, tt.y);
+                d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+                d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+                cd f[3];
+                f[0] = node_eval(d, omega);
+                const cd nv = c_nv * mk(ww.x, ww.y);
+                f[1] = f[0] * nv;
+                f[2] = f[1] * nv;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    if (s & 1) {
+                        fplus[m] = f[m];
+                    } else {
+                        const int q = s >> 1;
+                        const cd fs = s == 0 ? f[m] : fplus[m] + f[m];
+                        K[m] = K[m] + WK[q] * fs;
+                        if ((q & 1) == 0) G[m] = G[m] + WG[q >> 1] * fs;
+                    }
+                }
+            };
+            // two record loads in flight while a third record is being evaluated
+            NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
+            double2 t0 = tp[node_of(0)], t1 = tp[node_of(1)], t2;
+            double2 w0 = wp[node_of(0)], w1 = wp[node_of(1)], w2;
+#pragma unroll 1
+            for (int s = 0; s < PTS; s += 3) {
+                if (s + 2 < PTS) r2 = rp[node_of(s + 2)], t2 = tp[node_of(s + 2)], w2 = wp[node_of(s + 2)];
+                proc(r0, t0, w0, s);
+                if (s + 3 < PTS) r0 = rp[node_of(s + 3)], t0 = tp[node_of(s + 3)], w0 = wp[node_of(s + 3)];
+                if (s + 1 < PTS) proc(r1, t1, w1, s + 1);
+                if (s + 4 < PTS) r1 = rp[node_of(s + 4)], t1 = tp[node_of(s + 4)], w1 = wp[node_of(s + 4)];
+                if (s + 2 < PTS) proc(r2, t2, w2, s + 2);
+            }
+            // per moment: include/functions.h:203-208, 231-247
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (key[m] != cur) continue;
+                ++count[m];
+                const double dKx = K[m].x - G[m].x, dKy = K[m].y - G[m].y;
+                const double absK = sqrt(fma(K[m].x, K[m].x, K[m].y * K[m].y));
+                double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
+                const cd integral = mk(K[m].x * scale, K[m].y * scale);
+                err *= scale;
+                const double rel_abs = P.rel_tol * (absK * scale);
+                if (abs_tol[m] == 0.0) abs_tol[m] = rel_abs;
+                bool split = depth < P.max_sub && err > abs_tol[m] * inv_scale + P.prec_goal &&
+                             err > rel_abs + P.prec_goal;
+                if (split && (depth >= KD || count[m] >= (1 << 18))) {
+                    split = false;
+                    bad = 1;
+                }
+                if (split) {
+                    key[m] = make_key(depth + 1, path << 1);
+                } else {
+                    sum[m] = sum[m] + integral;
+                    unsigned long long p2 = path + 1;
+                    const int tz = min(depth, (int)__builtin_ctzll(p2 | (1ull << 63)));
+                    p2 >>= tz;
+                    const int d2 = depth - tz;
+                    key[m] = d2 == 0 ? DONE : make_key(d2, p2);
+                }
+            }
+        }
+
+        // ---- results: blocks A (m = 0), B and its mirrors (m = 1), D (m = 2) --------------------
+        if (mine) {
+            const double dg = gtab[i] - gtab[j], de = eta[i] - eta[j];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (deferred[m]) continue;
+                my_intervals += (unsigned long long)count[m];
+                cd kap = mk(P.pref * sum[m].y, -(P.pref * sum[m].x));  // -i pref sum, Parameters.cpp:182
+                if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+                kap = kap + kappa_e(m, P, de, dg, omega);
+                if (m == 0) {
+                    const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
+                    store(i, j, v);
+                    store(j, i, v);
+                } else if (m == 1) {
+                    const cd v = P.dx * kap;
+                    store(i, j + N, v);
+                    store(j, i + N, -v);
+                    store(i + N, j, -v);
+                    store(j + N, i, v);
+                } else {
+                    const cd v = P.dx * kap;
+                    store(i + N, j + N, v);
+                    store(j + N, i + N, v);
+                }
+            }
+        }
+    }
+
+    if (has_w) {
+        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
+        if (bad) A.status[b] = 1;
+    }
+}
+
 }  // namespace
 
 // part -1 = main buffer (full tree + subtree 0), part k >= 0 = run-time subtree k+1
@@ -350,7 +599,7 @@ size_t node_ttab_bytes(int gk_points, int max_intervals) {
 }
 
 hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
-                             void* recs, void* ttab, double* scale, hipStream_t stream) {
+                             void* recs, void* ttab, void* wtab, double* scale, hipStream_t stream) {
     CacheArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -360,6 +609,7 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, in
     A.omi = omi;
     A.recs = (NodeRec*)recs;
     A.ttab = (double2*)ttab;
+    A.wtab = (double2*)wtab;
     A.scale = scale;
     A.part = part;
     A.first = part < 0 ? 0 : A.geom.base[part + 1];
@@ -391,6 +641,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
         A.recs[c] = (const NodeRec*)recs[c];
         for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k) A.recs_ext[c][k] = (const NodeRec*)recs_ext[c][k];
         A.ttab[c] = (const double2*)ttab[c];
+        A.wtab[c] = nullptr;
     }
     A.scale = scale;
     A.worklist = worklist;
@@ -418,6 +669,55 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
         hipLaunchKernelGGL(k_assemble_cached<15>, grid, block, lds, stream, A);
     else
         hipLaunchKernelGGL(k_assemble_cached<31>, grid, block, lds, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeom& g,
+                                  const void* const recs[2],
+                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                                  const void* const ttab[2], const void* const wtab[2], const double* scale,
+                                  unsigned long long* worklist, unsigned int* worklist_count,
+                                  unsigned long long* defer_info, const int* act_idx, int n_act,
+                                  const void* chunks, int nchunks, hipStream_t stream) {
+    AsmCachedArgs A;
+    A.chunks = (const int2*)chunks;
+    A.P = L.P;
+    A.tab = L.tab;
+    A.pairs = (const ushort2*)L.pairs;
+    A.npairs = L.npairs;
+    A.geom = make_geom(g);
+    for (int c = 0; c < 2; ++c) {
+        A.recs[c] = (const NodeRec*)recs[c];
+        for (int k = 0; k < NODE_CACHE_MAX_SUB - 1; ++k) A.recs_ext[c][k] = (const NodeRec*)recs_ext[c][k];
+        A.ttab[c] = (const double2*)ttab[c];
+        A.wtab[c] = (const double2*)wtab[c];
+    }
+    A.scale = scale;
+    A.worklist = worklist;
+    A.worklist_count = worklist_count;
+    A.defer_info = defer_info;
+    A.act_idx = act_idx;
+    A.n_act = n_act;
+    A.omega = (const double2*)L.omega;
+    A.M = (double2*)L.M;
+    A.Mold = (const double2*)L.Mold;
+    A.Mp = (double2*)L.Mp;
+    A.domega = (const double2*)L.domega;
+    A.intervals = L.intervals;
+    A.status = L.status;
+    const int gw = L.gk_points == 15 ? 16 : 32;
+    const int groups_per_block = 256 / gw;
+    const long nitems = (long)L.npairs;  // an item is a pair
+    long want_groups = (nitems + L.items_per_group - 1) / L.items_per_group;
+    long gx = (want_groups + groups_per_block - 1) / groups_per_block;
+    if (gx < 1) gx = 1;
+    if (gx > 65535) gx = 65535;
+    dim3 grid((unsigned)gx, (unsigned)nchunks), block(256);
+    const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
+    if (L.gk_points == 15)
+        hipLaunchKernelGGL(k_assemble_cached_em<15>, grid, block, lds, stream, A);
+    else
+        hipLaunchKernelGGL(k_assemble_cached_em<31>, grid, block, lds, stream, A);
     return hipGetLastError();
 }
 

@@ -78,6 +78,8 @@ struct emme_ctx {
     void* d_recs[2] = {nullptr, nullptr};      // main part per contour class
     void* d_recs_ext[2][NODE_CACHE_MAX_SUB - 1] = {};  // run-time subtrees per class
     void* d_ttab[2] = {nullptr, nullptr};      // T table per class
+    void* d_wtab[2] = {nullptr, nullptr};      // moment-factor table per class (shared EM layout)
+    bool em_shared = false;    // nm == 3: one record per (pair, interval, node), three moments per lane
     bool ext_failed = false;
     unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
     double cache_bytes_used = 0.0;
@@ -253,11 +255,14 @@ int items_per_group_for(const emme_ctx* c, long units) {
     return (int)ipg;
 }
 
+// items the node cache is indexed by: (pair, moment), or pairs alone in the shared EM layout
+long cache_items(const emme_ctx* c) { return (long)c->npairs * (c->em_shared ? 1 : c->nm); }
+
 // Make sure the main part of the node cache of contour class `cls` (0: omi=+1, 1: omi=-1)
 // exists.  Returns false (and disables the cache) if it does not fit the budget.
 bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->cache_depth == -2) return false;
-    const long nitems = (long)c->npairs * c->nm;
+    const long nitems = cache_items(c);
     const double budget = c->cache_budget_gb * (double)(1 << 30);
     if (c->cache_depth == -1) {
         // full tree to depth dfull + the fixed subtree under the rightmost depth-5 node (that is
@@ -286,6 +291,8 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->cache_bytes_used + (double)bytes > budget ||
         hipMalloc(&c->d_recs[cls], bytes) != hipSuccess ||
         hipMalloc(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
+        (c->em_shared &&
+         hipMalloc(&c->d_wtab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess) ||
         (!c->d_scale &&
          hipMalloc((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
         (void)hipGetLastError();
@@ -297,7 +304,7 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     c->cache_bytes_used += (double)bytes;
     ScopedSpan s(c, K_OTHER);
     if (launch_node_cache(L, c->cache_geom, -1, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_ttab[cls],
-                          c->d_scale, c->stream) != hipSuccess) {
+                          c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess) {
         c->cache_depth = -2;
         return false;
     }
@@ -312,7 +319,7 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         }
         c->cache_bytes_used += (double)eb;
         (void)launch_node_cache(L, c->cache_geom, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1],
-                                c->d_ttab[cls], c->d_scale, c->stream);
+                                c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->stream);
     }
     return true;
 }
@@ -331,7 +338,7 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
     g.rp[k] = path >> (depth - rd);
     g.dd[k] = rd + 8;
     g.nsub = k + 1;
-    const long nitems = (long)c->npairs * c->nm;
+    const long nitems = cache_items(c);
     const double budget = c->cache_budget_gb * (double)(1 << 30);
     const size_t eb = node_cache_bytes(L.gk_points, nitems, g, k - 1);
     bool any = false;
@@ -347,7 +354,7 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
         c->cache_bytes_used += (double)eb;
         ScopedSpan s(c, K_OTHER);
         if (launch_node_cache(L, g, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1], c->d_ttab[cls],
-                              c->d_scale, c->stream) != hipSuccess)
+                              c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess)
             c->ext_failed = true;
         any = true;
     }
@@ -471,14 +478,19 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         c->last_fill_mode = 2;
         if (n_lane) {
             ScopedSpan s(c, K_ASM);
-            HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale,
-                                           c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx,
-                                           n_lane, c->d_chunks, nchunks, c->stream));
+            if (c->em_shared)
+                HIP_TRY(launch_assemble_cached_em(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_wtab,
+                                                  c->d_scale, c->d_worklist, c->d_worklist_count, c->d_defer_info,
+                                                  c->d_actidx, n_lane, c->d_chunks, nchunks, c->stream));
+            else
+                HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale,
+                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx,
+                                               n_lane, c->d_chunks, nchunks, c->stream));
         }
         if (n_lane) {
             ScopedSpan s(c, K_DEFER);
             HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
-                                         c->d_recs_ext, c->d_ttab, c->stream));
+                                         c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->stream));
         }
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
@@ -555,6 +567,9 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
     c->dim = es ? N : 2 * N;
     c->nm = es ? 1 : 3;
+    // electromagnetic contexts share one node record per (pair, interval, node) between the three
+    // moments (EMME_EM_SHARED=0: one record per moment, for A/B comparisons)
+    c->em_shared = !es && !(std::getenv("EMME_EM_SHARED") && std::atoi(std::getenv("EMME_EM_SHARED")) == 0);
 
     DevParams& P = c->P;
     std::vector<double> tab(3 * (size_t)N);
@@ -615,7 +630,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (int k = 0; k < 2; ++k) {
-        F(c->d_recs[k]), F(c->d_ttab[k]);
+        F(c->d_recs[k]), F(c->d_ttab[k]), F(c->d_wtab[k]);
         for (int e = 0; e < NODE_CACHE_MAX_SUB - 1; ++e) F(c->d_recs_ext[k][e]);
     }
     F(c->d_scale);

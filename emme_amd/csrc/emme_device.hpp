@@ -420,6 +420,21 @@ __device__ __forceinline__ NodeData node_data(double x, const DevParams& P, cons
     return d;
 }
 
+// The moment factor: F_m = F_0 * norm_vel^m with norm_vel = c_nv * W, W = conj(e) / t (pair-
+// independent; src/Parameters.cpp:142, 158-161).  Electromagnetic fills keep ONE record per
+// (pair, interval, node) -- the m = 0 one -- and a table of W per (interval, node).
+__device__ __forceinline__ cd node_w(double x, const DevParams& P, double omi) {
+    double sx, cx;
+    sincos(x, &sx, &cx);
+    const double rsc = frcp(sx * cx);
+    const double inv_cx = sx * rsc;
+    const double t = sx * inv_cx;
+    const double inv_t = cx * (cx * rsc);
+    const double u = t * P.inv_arc;
+    const double r1 = frsqrt(fma(u, u, 1.0));
+    return mk(inv_t * r1, inv_t * ((omi * u) * r1));  // (1/t) conj(e), e = r1 (1 - i omi u)
+}
+
 // omega-dependent half: one complex exponential and three complex products.
 __device__ __forceinline__ cd node_eval(const NodeData& d, cd omega) {
     const cd arg = d.A0 + d.T * omega;

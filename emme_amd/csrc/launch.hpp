@@ -39,7 +39,7 @@ struct AssembleLaunch {
 hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const NodeCacheGeom* g = nullptr,
                            const void* const recs[2] = nullptr,
                            const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1] = nullptr,
-                           const void* const ttab[2] = nullptr);
+                           const void* const ttab[2] = nullptr, const void* const wtab[2] = nullptr);
 // omega-lane form (assemble_wl.hip): the n_act batch items listed in act_idx (device) share
 // the omega-independent node data; L.active is ignored.
 hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n_act,
@@ -49,8 +49,19 @@ hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n
 size_t node_cache_bytes(int gk_points, long nitems, const NodeCacheGeom& g, int part);
 size_t node_ttab_bytes(int gk_points, int max_intervals);
 int node_cache_intervals(const NodeCacheGeom& g);
+// wtab != null: electromagnetic SHARED layout -- one record per (pair, interval, node), that of
+// moment 0, plus the table of moment factors W (see emme_device.hpp::node_w)
 hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
-                             void* recs, void* ttab, double* scale, hipStream_t stream);
+                             void* recs, void* ttab, void* wtab, double* scale, hipStream_t stream);
+// electromagnetic fill on the shared layout: a lane walks the three moments of a pair together
+hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeom& g,
+                                     const void* const recs[2],
+                                     const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
+                                     const void* const ttab[2], const void* const wtab[2],
+                                     const double* scale, unsigned long long* worklist,
+                                     unsigned int* worklist_count, unsigned long long* defer_info,
+                                     const int* act_idx, int n_act, const void* chunks, int nchunks,
+                                     hipStream_t stream);
 hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g,
                                   const void* const recs[2],
                                   const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
@@ -64,7 +75,8 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const unsigned int* count, const NodeCacheGeom* g,
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
-                                const void* const ttab[2], hipStream_t stream);
+                                const void* const ttab[2], const void* const wtab[2],
+                                hipStream_t stream);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,

