@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
     const int worker = (blockIdx.x * GROUPS_PER_BLOCK + group_in_block) * nsub + sub;
     const int nworkers = gridDim.x * GROUPS_PER_BLOCK * nsub;
 
+    const TransConsts TC = trans_consts();  // polynomial coefficients, once, in scalar registers
     unsigned long long my_intervals = 0;
     int bad = 0;
     // Item loop: the lanes of a wave take their next items together and walk their own trees
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
                 d.T = mk(tt.x, tt.y);
                 d.Q1 = mk(rec.Q1.x, rec.Q1.y);
                 d.Q0 = mk(rec.Q0.x, rec.Q0.y);
-                const cd f = node_eval(d, omega);
+                const cd f = node_eval(d, omega, TC);
                 if (s & 1) {
                     fplus = f;
                 } else {
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     };
     const unsigned long long DONE = ~0ull;
 
+    const TransConsts TC = trans_consts();  // polynomial coefficients, once, in scalar registers
     unsigned long long my_intervals = 0;
     int bad = 0;
     for (int item = worker; __ballot(has_w && item < nitems) != 0ull; item += nworkers) {
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
                 d.Q1 = mk(rec.Q1.x, rec.Q1.y);
                 d.Q0 = mk(rec.Q0.x, rec.Q0.y);
                 cd f[3];
-                f[0] = node_eval(d, omega);
+                f[0] = node_eval(d, omega, TC);
                 const cd nv = c_nv * mk(ww.x, ww.y);
                 f[1] = f[0] * nv;
                 f[2] = f[1] * nv;

@@ -156,6 +156,82 @@ __device__ __forceinline__ double fexp(double x) {
     return ldexp(p, (int)k);
 }
 
+// The same two kernels with their coefficients handed in: a caller that evaluates many nodes
+// (the unrolled cached fill) loads them ONCE into scalar registers instead of once per use.
+struct TransConsts {
+    double two_over_pi, pio2_1, pio2_2, pio2_3;
+    double s1, s2, s3, s4, s5, s6;
+    double c1, c2, c3, c4, c5, c6;
+    double log2e, ln2_hi, ln2_lo;
+    double e13, e12, e11, e10, e9, e8, e7, e6, e5, e4, e3;
+};
+__device__ __forceinline__ TransConsts trans_consts() {
+    TransConsts k;
+    k.two_over_pi = sreg(0.63661977236758134308);
+    k.pio2_1 = sreg(1.5707963267948965580e+00);
+    k.pio2_2 = sreg(6.1232339957367660359e-17);
+    k.pio2_3 = sreg(-1.4973849048591698329e-33);
+    k.s1 = sreg(1.58969099521155010221e-10), k.s2 = sreg(-2.50507602534068634195e-08);
+    k.s3 = sreg(2.75573137070700676789e-06), k.s4 = sreg(-1.98412698298579493134e-04);
+    k.s5 = sreg(8.33333333332248946124e-03), k.s6 = sreg(-1.66666666666666324348e-01);
+    k.c1 = sreg(-1.13596475577881948265e-11), k.c2 = sreg(2.08757232129817482790e-09);
+    k.c3 = sreg(-2.75573143513906633035e-07), k.c4 = sreg(2.48015872894767294178e-05);
+    k.c5 = sreg(-1.38888888888741095749e-03), k.c6 = sreg(4.16666666666666019037e-02);
+    k.log2e = sreg(1.4426950408889634074);
+    k.ln2_hi = sreg(6.93147180369123816490e-01), k.ln2_lo = sreg(1.90821492927058770002e-10);
+    k.e13 = sreg(1.6059043836821613e-10), k.e12 = sreg(2.0876756987868100e-09);
+    k.e11 = sreg(2.5052108385441720e-08), k.e10 = sreg(2.7557319223985888e-07);
+    k.e9 = sreg(2.7557319223985893e-06), k.e8 = sreg(2.4801587301587302e-05);
+    k.e7 = sreg(1.9841269841269841e-04), k.e6 = sreg(1.3888888888888889e-03);
+    k.e5 = sreg(8.3333333333333332e-03), k.e4 = sreg(4.1666666666666664e-02);
+    k.e3 = sreg(1.6666666666666666e-01);
+    return k;
+}
+__device__ __forceinline__ void fsincos(double x, double& s, double& c, const TransConsts& k) {
+    // two-term reduction: the third term of pi/2 (1.5e-33 n) is below 1e-17 for |n| < 6e15
+    const double n = rint(x * k.two_over_pi);
+    double r = fma(-n, k.pio2_1, x);
+    r = fma(-n, k.pio2_2, r);
+    const double z = r * r;
+    double ps = fma(z, k.s1, k.s2);
+    ps = fma(z, ps, k.s3);
+    ps = fma(z, ps, k.s4);
+    ps = fma(z, ps, k.s5);
+    ps = fma(z, ps, k.s6);
+    const double sn = fma(r * z, ps, r);
+    double pc = fma(z, k.c1, k.c2);
+    pc = fma(z, pc, k.c3);
+    pc = fma(z, pc, k.c4);
+    pc = fma(z, pc, k.c5);
+    pc = fma(z, pc, k.c6);
+    const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));  // |error| <= 1 ulp of 1
+    const int q = (int)n & 3;
+    const double s0 = (q & 1) ? cs : sn;
+    const double c0 = (q & 1) ? sn : cs;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ double fexp(double x, const TransConsts& k) {
+    const double kk = rint(x * k.log2e);
+    double r = fma(-kk, k.ln2_hi, x);
+    r = fma(-kk, k.ln2_lo, r);
+    double p = k.e13;
+    p = fma(p, r, k.e12);
+    p = fma(p, r, k.e11);
+    p = fma(p, r, k.e10);
+    p = fma(p, r, k.e9);
+    p = fma(p, r, k.e8);
+    p = fma(p, r, k.e7);
+    p = fma(p, r, k.e6);
+    p = fma(p, r, k.e5);
+    p = fma(p, r, k.e4);
+    p = fma(p, r, k.e3);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kk);
+}
+
 // Scalars shared by every work item of a launch (passed by value as a kernel argument).
 struct DevParams {
     int N;        // grid points
@@ -444,6 +520,17 @@ __device__ __forceinline__ cd node_eval(const NodeData& d, cd omega) {
     double sa, ca;
     fsincos(arg.y, sa, ca);
     const double ea = fexp(arg.x);
+    return mk(ea * ca, ea * sa) * (omega * d.Q1 + d.Q0);
+}
+
+__device__ __forceinline__ cd node_eval(const NodeData& d, cd omega, const TransConsts& k) {
+    const cd arg = d.A0 + d.T * omega;
+    if (!(arg.x >= -40.)) {
+        if (arg.x < -40.) return mk(0.0, 0.0);  // safe_exp clamp, src/Parameters.cpp:167-173
+    }
+    double sa, ca;
+    fsincos(arg.y, sa, ca, k);
+    const double ea = fexp(arg.x, k);
     return mk(ea * ca, ea * sa) * (omega * d.Q1 + d.Q0);
 }
 
