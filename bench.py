@@ -125,11 +125,11 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this build
     (profiles/, separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md); bench.py cannot
     collect hardware counters itself.  Raw counter figures (no gfx950 x2 read correction)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v5_pmc_summary.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v6_pmc_summary.json")
     try:
         k = json.load(open(path))["kernels"][kernel]
         return (k["hbm_fetch_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
-                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v5_pmc_summary.json "
+                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v6_pmc_summary.json "
                 "(rocprofv3 --pmc passes over tools/iter_profile.py, same workload)")
     except (OSError, KeyError, ValueError):
         return None, "no PMC summary for this kernel under profiles/"
@@ -266,9 +266,13 @@ def main():
                 "frac": (bytes_alg / asm_s / 1e9) / HBM_PEAK_GBS if asm_s > 0 else 0.0,
                 "algorithmic_bytes_per_launch": bytes_alg / n_launch,
                 "traffic": traffic, "traffic_note": traffic_note,
+                # what actually crossed the HBM interface (PMC) over the measured launch time
+                "hbm_measured_GBps": (traffic / (asm_s / n_launch) / 1e9) if (traffic and asm_s > 0) else None,
                 "note": "algorithmic bytes = node records consumed + matrix entries written, per second "
-                        "of the main fill kernel; most record reads are served by L2 / Infinity Cache "
-                        "(measured HBM-side FETCH_SIZE per launch: see profiles/)",
+                        "of the main fill kernel. About 80 % of the record reads are served by L1 / L2 / "
+                        "Infinity Cache (the omegas of a chunk read the same records), so this figure can "
+                        "exceed the HBM peak; `traffic` / `hbm_measured_GBps` are the bytes that really "
+                        "crossed the HBM interface (raw FETCH_SIZE + WRITE_SIZE, no x2 correction)",
             },
             "node_cache_gib": ctx.node_cache_gib(),
             "kernels_ms_per_step": {
