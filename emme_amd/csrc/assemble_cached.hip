@@ -139,7 +139,7 @@ template <int PTS>
 __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(AsmCachedArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int H = (PTS + 1) / 2;
-    constexpr int NODE_UNROLL = PTS == 15 ? 5 : 1;  // trips of the 3-node loop unrolled
+    constexpr int NODE_UNROLL = PTS == 15 ? 5 : 3;  // trips of the 3-node loop unrolled
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     extern __shared__ double lds_raw[];  // eta | g | b
 
@@ -359,7 +359,7 @@ template <int PTS>
 __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int H = (PTS + 1) / 2;
-    constexpr int NODE_UNROLL = PTS == 15 ? 5 : 1;  // trips of the 3-node loop unrolled
+    constexpr int NODE_UNROLL = PTS == 15 ? 5 : 3;  // trips of the 3-node loop unrolled
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     constexpr int KD = 56;  // key layout: depth <= KD
     extern __shared__ double lds_raw[];  // eta | g | b | scale table
