@@ -15,9 +15,12 @@
 // finishing each with one complex exponential and three complex products.  No idle lanes, no
 // cross-lane reduction, summation in the reference's order.
 //   * k_node_cache   fills the cache: one 16/32-lane group per (item, interval), lane = node.
-//   * k_assemble_cached  the fill.  An integral that needs an interval deeper than D (rare:
-//     strongly damped omegas) is handed over whole, through a device-side work list, to the
-//     lanes-are-nodes kernel (assemble.hip, list mode), which recomputes it on the fly.
+//   * k_assemble_cached  the fill (electrostatic: one integral per pair).  An integral that
+//     needs an interval outside the cache (rare: strongly damped omegas) is handed over whole,
+//     through a device-side work list, to the cooperative kernel (assemble.hip,
+//     k_assemble_coop: a workgroup per integral), which starts it over.
+//   * k_assemble_cached_em  the electromagnetic fill: the three moments of a pair share one
+//     record per node and one walk over the union of their trees.
 #include <hip/hip_runtime.h>
 
 #include "assemble_common.hpp"
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
             const int cslot = A.geom.slot(depth, path, which);
             const NodeRec* ebuf = which >= 0 ? A.recs_ext[cls][which] : recs;
             if (cslot < 0 || ebuf == nullptr) {
-                // outside the cache: hand the whole integral to the on-the-fly kernel
+                // outside the cache: hand the whole integral to the cooperative kernel
                 const unsigned int slot = atomicAdd(A.worklist_count, 1u);
                 // bits 58..63: depth, bits 17..57: low path bits (diagnostics only; the list
                 // kernel masks them off), bits 32..47 would collide with b, so b sits at 17+24

@@ -85,7 +85,7 @@ struct emme_ctx {
     double cache_bytes_used = 0.0;
     unsigned int last_deferred = 0;            // integrals the previous cached fill deferred
     double* d_scale = nullptr;  // half-widths of the cached intervals
-    unsigned long long* d_worklist = nullptr;  // integrals deferred to the on-the-fly kernel
+    unsigned long long* d_worklist = nullptr;  // integrals deferred to the cooperative kernel
     unsigned int* d_worklist_count = nullptr;
     size_t worklist_cap = 0;
     double cache_budget_gb = 176.0;  // both classes together (MI355X: 288 GB of HBM3E)

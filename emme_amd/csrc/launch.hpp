@@ -70,7 +70,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
                                   unsigned long long* defer_info, const int* act_idx, int n_act,
                                   const void* chunks /*int2[nchunks]: (first, size)*/, int nchunks,
                                   hipStream_t stream);
-// integrals deferred by the cached kernel, recomputed by the lanes-are-nodes kernel
+// integrals deferred by the cached kernels, recomputed by k_assemble_coop (a workgroup each)
 hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
                                 const unsigned int* count, const NodeCacheGeom* g,
                                 const void* const recs[2],
