@@ -499,3 +499,31 @@ def test_full_size_newton_step_properties(emme, oracle, case):
     scale = np.abs(Mchk).max()
     assert np.abs(Mn[0] - Mchk).max() <= 1e-12 * scale
     assert np.abs(Mpn[0] - (Mn[0] - M1) / dw_tr[0]).max() <= 1e-9 * np.abs(Mpn[0]).max()
+
+
+def test_degenerate_batches_and_bad_arguments(emme, oracle):
+    """Empty / single-item / zero-step-limit calls and argument errors at the ABI (no crash, the
+    documented codes)."""
+    import ctypes as C
+    d = example_tokamak(npoints=16)
+    po = oracle.params(d)
+    with _ctx(emme, d) as ctx:
+        lib, h = ctx.lib, ctx.h
+        w = np.array([-0.8 + 0.25j])
+        out = np.zeros(2)
+        it = np.zeros(1, dtype=np.int32)
+        inf = np.zeros(1, dtype=np.int32)
+        # empty batch, null pointers, negative limit
+        assert lib.emme_solve_roots(h, w.ctypes.data, 0, 1e-6, 20, out.ctypes.data, it.ctypes.data, inf.ctypes.data, None) == -1
+        assert lib.emme_solve_roots(h, None, 1, 1e-6, 20, out.ctypes.data, it.ctypes.data, inf.ctypes.data, None) == -1
+        assert lib.emme_solve_roots(h, w.ctypes.data, 1, 1e-6, -1, out.ctypes.data, it.ctypes.data, inf.ctypes.data, None) == -1
+        assert lib.emme_assemble_batch(h, w.ctypes.data, 0, out.ctypes.data, None) == -1
+        assert lib.emme_ctx_get_matrix(h, 5, out.ctypes.data) == -1  # no such chain
+        # unknown iteration method
+        M = np.zeros((1, 16, 16), dtype=np.complex128)
+        assert lib.emme_newton_step_batch(h, w.ctypes.data, out.ctypes.data, 1, M.ctypes.data, M.ctypes.data, 7,
+                                          inf.ctypes.data) == -1
+        # step limit 0: exactly one Newton step (src/main.cpp:43 runs j = 0..limit), a single chain
+        roots, iters, info, its = ctx.solve_roots([-0.8 + 0.25j], step_limit=0, want_iterates=True)
+        r_or, its_or, _, _ = oracle.solve_root(po, -0.8 + 0.25j)
+        assert iters[0] == 1 and abs(roots[0] - its_or[0]) <= TOL_W and abs(its[0, 0] - its_or[0]) <= TOL_W
