@@ -205,11 +205,16 @@ __device__ __forceinline__ void fsincos(double x, double& s, double& c, const Tr
     pc = fma(z, pc, k.c5);
     pc = fma(z, pc, k.c6);
     const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));  // |error| <= 1 ulp of 1
-    const int q = (int)n & 3;
-    const double s0 = (q & 1) ? cs : sn;
-    const double c0 = (q & 1) ? sn : cs;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
+    // quadrant q = n mod 4: (cos, sin)(x) = rotation of (cs, sn) by q quarter turns; the signs go
+    // straight into the sign bits
+    const unsigned q = (unsigned)(int)n;
+    const bool odd = (q & 1u) != 0u;
+    const double s0 = odd ? cs : sn;
+    const double c0 = odd ? sn : cs;
+    const unsigned long long sbit = (unsigned long long)(q & 2u) << 62;
+    const unsigned long long cbit = (unsigned long long)((q + 1u) & 2u) << 62;
+    s = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s0) ^ sbit));
+    c = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(c0) ^ cbit));
 }
 __device__ __forceinline__ double fexp(double x, const TransConsts& k) {
     const double kk = rint(x * k.log2e);
@@ -524,14 +529,18 @@ __device__ __forceinline__ cd node_eval(const NodeData& d, cd omega) {
 }
 
 __device__ __forceinline__ cd node_eval(const NodeData& d, cd omega, const TransConsts& k) {
-    const cd arg = d.A0 + d.T * omega;
-    if (!(arg.x >= -40.)) {
-        if (arg.x < -40.) return mk(0.0, 0.0);  // safe_exp clamp, src/Parameters.cpp:167-173
+    // arg = A0 + T omega and S = omega Q1 + Q0 as fused chains (two FMAs per component)
+    const double ax = fma(d.T.x, omega.x, fma(-d.T.y, omega.y, d.A0.x));
+    if (!(ax >= -40.)) {
+        if (ax < -40.) return mk(0.0, 0.0);  // safe_exp clamp, src/Parameters.cpp:167-173
     }
+    const double ay = fma(d.T.x, omega.y, fma(d.T.y, omega.x, d.A0.y));
     double sa, ca;
-    fsincos(arg.y, sa, ca, k);
-    const double ea = fexp(arg.x, k);
-    return mk(ea * ca, ea * sa) * (omega * d.Q1 + d.Q0);
+    fsincos(ay, sa, ca, k);
+    const double ea = fexp(ax, k);
+    const cd S = mk(fma(omega.x, d.Q1.x, fma(-omega.y, d.Q1.y, d.Q0.x)),
+                    fma(omega.x, d.Q1.y, fma(omega.y, d.Q1.x, d.Q0.y)));
+    return mk(ea * ca, ea * sa) * S;
 }
 
 // Gauss-Kronrod node tables laid out per lane of a group (centre, +x_1..+x_h, -x_1..-x_h,
