@@ -58,7 +58,8 @@ struct AsmArgs {
 template <int GW>
 __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned long long path,
                                          long cache_item, int lane_in_group, double x,
-                                         const PairConst& pc, const OmegaConst& oc, int m) {
+                                         const PairConst& pc, const OmegaConst& oc, int m,
+                                         const TransConsts& tc) {
     const int cls = oc.omi > 0.0 ? 0 : 1;
     int which;
     const int cslot = A.recs[cls] ? A.geom.slot(depth, path, which) : -1;
@@ -86,7 +87,7 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
     } else {
         d = node_data(x, A.P, pc, oc.omi, m);
     }
-    return node_eval(d, oc.omega);
+    return node_eval(d, oc.omega, tc);
 }
 
 template <int PTS, bool LIST>
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
     extern __shared__ double lds_tab[];  // eta | g | b  (3N doubles) | per-group (mid, r) stack
 
     const DevParams& P = A.P;
+    const TransConsts TC = trans_consts();
     int b = LIST ? 0 : blockIdx.y;
     if (!LIST && A.active && A.active[b] == 0) return;
     const int N = P.N, dim = P.dim;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
 
         const long cache_item = LIST ? (long)(A.worklist[item] & 0xffffffffull) : (long)item;
         const cd f = (LIST || A.recs[oc.omi > 0.0 ? 0 : 1] != nullptr)
-                         ? node_value<GW>(A, depth, path, cache_item, lane_in_group, x, pc, oc, m)
+                         ? node_value<GW>(A, depth, path, cache_item, lane_in_group, x, pc, oc, m, TC)
                          : integrand(x, P, pc, oc, m);
         const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
         const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void k_assemble_coop(AsmArgs A) {
     __shared__ int s_bad;
 
     const DevParams& P = A.P;
+    const TransConsts TC = trans_consts();
     const int N = P.N, dim = P.dim;
     for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_tab[k] = A.tab[k];
     if (threadIdx.x == 0) s_bad = 0;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void k_assemble_coop(AsmArgs A) {
             mid = (r + l) / 2;
             const double scale = (r - l) / 2;
             const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
-            const cd f = node_value<GW>(A, depth, path, (long)it, lane_in_group, x, pc, oc, m);
+            const cd f = node_value<GW>(A, depth, path, (long)it, lane_in_group, x, pc, oc, m, TC);
             const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
             const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
             const double dKx = Kx - Gx, dKy = Ky - Gy;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
     extern __shared__ double lds_raw[];  // tables | interval stacks | node slots
 
     const DevParams& P = A.P;
+    const TransConsts TC = trans_consts();
     const int N = P.N, dim = P.dim;
     for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_raw[k] = A.tab[k];
     __syncthreads();
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
                     d.T = mk(s[1].x, s[1].y);
                     d.Q1 = mk(s[2].x, s[2].y);
                     d.Q0 = mk(s[3].x, s[3].y);
-                    return node_eval(d, omega);
+                    return node_eval(d, omega, TC);
                 };
                 // include/functions.h:186-201: centre, then f(+x_i) + f(-x_i) for i = 1..
                 const cd f0 = eval(0);
