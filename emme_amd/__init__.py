@@ -5,7 +5,9 @@ emme_amd/libemme_hip.so).  There is no CPU fallback: every compute entry point r
 if the HIP library or a gfx950 device is missing.
 """
 from ._lib import (EmmeError, Params, Profile, Context, params_from_json, params_from_dict,
-                   tables, weight, lib_path, load, json_text, null_vector, scan_values, run_json)
+                   tables, weight, lib_path, load, json_text, null_vector, scan_values, run_json,
+                   release_pooled_memory)
 
 __all__ = ["EmmeError", "Params", "Profile", "Context", "params_from_json", "params_from_dict",
-           "tables", "weight", "lib_path", "load", "json_text", "null_vector", "scan_values", "run_json"]
+           "tables", "weight", "lib_path", "load", "json_text", "null_vector", "scan_values", "run_json",
+           "release_pooled_memory"]

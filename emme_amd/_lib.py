@@ -89,6 +89,8 @@ def load():
     lib.emme_ctx_create.argtypes = [PP, C.c_int, C.POINTER(P)]
     lib.emme_ctx_destroy.argtypes = [P]
     lib.emme_ctx_destroy.restype = None
+    lib.emme_release_pooled_memory.argtypes = []
+    lib.emme_release_pooled_memory.restype = None
     lib.emme_ctx_set_stream.argtypes = [P, P]
     lib.emme_ctx_dim.argtypes = [P]
     lib.emme_ctx_fill_mode.argtypes = [P]
@@ -200,6 +202,11 @@ def run_json(text: str, matrix_dir: str | None = None) -> dict:
         return json.loads(C.string_at(out).decode())
     finally:
         load().emme_free(out)
+
+
+def release_pooled_memory() -> None:
+    """Give the node-cache buffers kept from destroyed contexts back to the driver."""
+    load().emme_release_pooled_memory()
 
 
 def _c128(a, shape=None):

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -71,11 +72,14 @@ struct emme_ctx {
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
     int last_fill_mode = -1;   // kernel family of the last fill: 0 nodes, 1 omega-lane, 2 cached
     int wl_min = 4;            // use the omega-lane kernel from this many active items on
+    int cache_min_batch = 8;   // build the node cache only for calls with at least this many omegas
     // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
     int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
     NodeCacheGeom cache_geom{};
     int cache_max_intervals = 0;  // capacity of the T / scale tables
     void* d_recs[2] = {nullptr, nullptr};      // main part per contour class
+    size_t recs_bytes[2] = {0, 0};
+    size_t recs_ext_bytes[2][NODE_CACHE_MAX_SUB - 1] = {};
     void* d_recs_ext[2][NODE_CACHE_MAX_SUB - 1] = {};  // run-time subtrees per class
     void* d_ttab[2] = {nullptr, nullptr};      // T table per class
     void* d_wtab[2] = {nullptr, nullptr};      // moment-factor table per class (shared EM layout)
@@ -106,6 +110,65 @@ struct emme_ctx {
 };
 
 namespace {
+
+// Process-wide pool of the big node-cache buffers.  Allocating ~150 GB takes seconds, far longer
+// than filling it, and a parameter sweep creates one context per parameter set: buffers of a
+// destroyed context are kept and handed to the next one (the records are recomputed anyway).
+struct PoolEntry {
+    void* ptr;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::vector<PoolEntry> g_pool;
+
+void pool_release_all() {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (auto& e : g_pool) {
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.ptr);
+    }
+    g_pool.clear();
+}
+
+hipError_t pool_alloc(void** out, size_t bytes, int device) {
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        int best = -1;
+        for (int k = 0; k < (int)g_pool.size(); ++k)
+            if (g_pool[k].device == device && g_pool[k].bytes >= bytes && g_pool[k].bytes <= bytes + bytes / 4 &&
+                (best < 0 || g_pool[k].bytes < g_pool[best].bytes))
+                best = k;
+        if (best >= 0) {
+            *out = g_pool[best].ptr;
+            g_pool.erase(g_pool.begin() + best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {  // give the pooled memory back to the driver and try once more
+        (void)hipGetLastError();
+        pool_release_all();
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
+void pool_free(void* p, size_t bytes, int device) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_pool.push_back({p, bytes, device});
+    // keep at most ~one large context's worth; evict the oldest buffers beyond that
+    size_t total = 0;
+    for (const auto& e : g_pool) total += e.bytes;
+    while (total > (size_t)200e9 && !g_pool.empty()) {
+        (void)hipSetDevice(g_pool.front().device);
+        (void)hipFree(g_pool.front().ptr);
+        total -= g_pool.front().bytes;
+        g_pool.erase(g_pool.begin());
+    }
+    (void)hipSetDevice(device);
+}
 
 size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
 
@@ -289,19 +352,20 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->d_recs[cls]) return true;
     const size_t bytes = node_cache_bytes(L.gk_points, nitems, c->cache_geom, -1);
     if (c->cache_bytes_used + (double)bytes > budget ||
-        hipMalloc(&c->d_recs[cls], bytes) != hipSuccess ||
+        pool_alloc(&c->d_recs[cls], bytes, c->device) != hipSuccess ||
         hipMalloc(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
         (c->em_shared &&
          hipMalloc(&c->d_wtab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess) ||
         (!c->d_scale &&
          hipMalloc((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
         (void)hipGetLastError();
-        if (c->d_recs[cls]) (void)hipFree(c->d_recs[cls]);
+        pool_free(c->d_recs[cls], bytes, c->device);
         c->d_recs[cls] = nullptr;
         c->cache_depth = -2;  // fall back to the on-the-fly kernels for good
         return false;
     }
     c->cache_bytes_used += (double)bytes;
+    c->recs_bytes[cls] = bytes;
     ScopedSpan s(c, K_OTHER);
     if (launch_node_cache(L, c->cache_geom, -1, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_ttab[cls],
                           c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess) {
@@ -312,12 +376,13 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     for (int k = 1; k < c->cache_geom.nsub; ++k) {
         const size_t eb = node_cache_bytes(L.gk_points, nitems, c->cache_geom, k - 1);
         if (c->cache_bytes_used + (double)eb > budget) break;
-        if (hipMalloc(&c->d_recs_ext[cls][k - 1], eb) != hipSuccess) {
+        if (pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
             (void)hipGetLastError();
             c->d_recs_ext[cls][k - 1] = nullptr;
             break;
         }
         c->cache_bytes_used += (double)eb;
+        c->recs_ext_bytes[cls][k - 1] = eb;
         (void)launch_node_cache(L, c->cache_geom, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1],
                                 c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->stream);
     }
@@ -345,13 +410,14 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
     for (int cls = 0; cls < 2; ++cls) {
         if (!need[cls] || !c->d_recs[cls]) continue;
         if (c->cache_bytes_used + (double)eb > budget ||
-            hipMalloc(&c->d_recs_ext[cls][k - 1], eb) != hipSuccess) {
+            pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
             (void)hipGetLastError();
             c->d_recs_ext[cls][k - 1] = nullptr;
             c->ext_failed = true;
             break;
         }
         c->cache_bytes_used += (double)eb;
+        c->recs_ext_bytes[cls][k - 1] = eb;
         ScopedSpan s(c, K_OTHER);
         if (launch_node_cache(L, g, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1], c->d_ttab[cls],
                               c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess)
@@ -400,7 +466,11 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     if (cost)
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     // contour classes present among the omegas (needs their host values)
-    bool use_cache = host_omega != nullptr && c->cache_depth != -2;
+    // The cache costs a few hundred ms of kernels plus the allocation of up to ~170 GB to build
+    // and pays off after ~10 fills: a call with a handful of omegas (a single root of a
+    // parameter scan) goes through the on-the-fly kernels unless the cache already exists.
+    bool use_cache = host_omega != nullptr && c->cache_depth != -2 &&
+                     (nbatch >= c->cache_min_batch || c->d_recs[0] != nullptr || c->d_recs[1] != nullptr);
     if (use_cache) {
         bool need[2] = {false, false};
         for (int b : idx) need[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1] = true;
@@ -561,6 +631,7 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->p = *p;
     c->device = device;
     if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
+    if (const char* e = std::getenv("EMME_CACHE_MIN_BATCH")) c->cache_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("EMME_NODE_CACHE_GB")) c->cache_budget_gb = std::atof(e);
     const int N = p->npoints;
     c->N = N;
@@ -630,8 +701,10 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (int k = 0; k < 2; ++k) {
-        F(c->d_recs[k]), F(c->d_ttab[k]), F(c->d_wtab[k]);
-        for (int e = 0; e < NODE_CACHE_MAX_SUB - 1; ++e) F(c->d_recs_ext[k][e]);
+        // the big buffers go to the process-wide pool for the next context
+        pool_free(c->d_recs[k], c->recs_bytes[k], c->device);
+        F(c->d_ttab[k]), F(c->d_wtab[k]);
+        for (int e = 0; e < NODE_CACHE_MAX_SUB - 1; ++e) pool_free(c->d_recs_ext[k][e], c->recs_ext_bytes[k][e], c->device);
     }
     F(c->d_scale);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
@@ -639,6 +712,8 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     delete c;
 }
+
+void emme_release_pooled_memory(void) { pool_release_all(); }
 
 int emme_ctx_set_stream(emme_ctx_t* c, void* s) {
     if (!c) return EMME_EINVAL;

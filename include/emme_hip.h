@@ -82,6 +82,10 @@ double emme_weight(int n, int i, int j);
 /* One context per (device, parameter set). device < 0 => current device. */
 int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out);
 void emme_ctx_destroy(emme_ctx_t* ctx);
+/* The node-cache buffers of destroyed contexts (up to ~170 GB) are kept in a process-wide pool
+ * and reused by the next context (allocating them costs seconds, a parameter sweep creates one
+ * context per parameter set); this returns them to the driver. */
+void emme_release_pooled_memory(void);
 /* Launch everything on this hipStream_t (e.g. torch's current stream). NULL = default. */
 int emme_ctx_set_stream(emme_ctx_t* ctx, void* hip_stream);
 int emme_ctx_dim(const emme_ctx_t* ctx); /* N if beta_e == 0 else 2N */

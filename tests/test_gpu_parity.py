@@ -527,3 +527,26 @@ def test_degenerate_batches_and_bad_arguments(emme, oracle):
         roots, iters, info, its = ctx.solve_roots([-0.8 + 0.25j], step_limit=0, want_iterates=True)
         r_or, its_or, _, _ = oracle.solve_root(po, -0.8 + 0.25j)
         assert iters[0] == 1 and abs(roots[0] - its_or[0]) <= TOL_W and abs(its[0, 0] - its_or[0]) <= TOL_W
+
+
+def test_cache_policy_and_buffer_pool(emme, oracle, monkeypatch):
+    """Default policy: a call with fewer than 8 omegas does not build the node cache (a single
+    root of a parameter scan would pay seconds of allocation for nothing), a larger one does and
+    later small calls then use it; the big buffers of a destroyed context are reused by the next."""
+    monkeypatch.setenv("EMME_CACHE_MIN_BATCH", "8")
+    monkeypatch.setenv("EMME_NODE_CACHE_GB", "4")
+    d = example_tokamak(npoints=24)
+    po = oracle.params(d)
+    ws = np.array([-0.8 + 0.25j - 0.01j * k for k in range(9)])
+    Mo, _ = oracle.assemble(po, complex(ws[0]))
+    for _ in range(2):  # the second context takes its buffers from the pool
+        with _ctx(emme, d) as ctx:
+            M1 = ctx.assemble(ws[:2])
+            assert "cache" not in ctx.fill_kernel() and ctx.node_cache_gib() == 0.0
+            M9 = ctx.assemble(ws)
+            assert "cache" in ctx.fill_kernel() and ctx.node_cache_gib() > 0.0
+            M2 = ctx.assemble(ws[:2])
+            assert "cache" in ctx.fill_kernel()
+            for M in (M1[0], M9[0], M2[0]):
+                assert np.abs(M - Mo).max() <= TOL_M * np.abs(Mo).max()
+    emme.release_pooled_memory()
