@@ -154,6 +154,17 @@ hipError_t pool_alloc(void** out, size_t bytes, int device) {
     return e;
 }
 
+// hipMalloc that gives pooled cache buffers back to the driver before reporting out-of-memory
+hipError_t malloc_retry(void** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_release_all();
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
 void pool_free(void* p, size_t bytes, int device) {
     if (!p) return;
     std::lock_guard<std::mutex> g(g_pool_mu);
@@ -233,18 +244,18 @@ int ensure_batch(emme_ctx* c, int nb) {
     F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active), F(c->d_iters), F(c->d_info),
         F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks);
     c->cap = 0;
-    HIP_TRY(hipMalloc((void**)&c->d_omega, sizeof(double) * 2 * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_domega, sizeof(double) * 2 * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_tr, sizeof(double) * 2 * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_active, sizeof(int) * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_iters, sizeof(int) * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_info, sizeof(int) * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(int) * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_actidx, sizeof(int) * nb));
-    HIP_TRY(hipMalloc((void**)&c->d_chunks, sizeof(int) * 2 * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_omega, sizeof(double) * 2 * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_domega, sizeof(double) * 2 * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_tr, sizeof(double) * 2 * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_active, sizeof(int) * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_iters, sizeof(int) * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_info, sizeof(int) * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_status, sizeof(int) * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_actidx, sizeof(int) * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_chunks, sizeof(int) * 2 * nb));
     if (!c->d_rounds) {
-        HIP_TRY(hipMalloc((void**)&c->d_rounds, sizeof(unsigned long long)));
+        HIP_TRY(malloc_retry((void**)&c->d_rounds, sizeof(unsigned long long)));
         HIP_TRY(hipMemset(c->d_rounds, 0, sizeof(unsigned long long)));
     }
     c->cap = nb;
@@ -262,10 +273,10 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
         c->mat_cap = nb;
     }
     const size_t bytes = mat_doubles(c) * sizeof(double) * (size_t)c->mat_cap;
-    if ((sets & 1) && !c->d_M) HIP_TRY(hipMalloc((void**)&c->d_M, bytes));
-    if ((sets & 2) && !c->d_Mold) HIP_TRY(hipMalloc((void**)&c->d_Mold, bytes));
-    if ((sets & 4) && !c->d_Mp) HIP_TRY(hipMalloc((void**)&c->d_Mp, bytes));
-    if ((sets & 8) && !c->d_work) HIP_TRY(hipMalloc((void**)&c->d_work, bytes));
+    if ((sets & 1) && !c->d_M) HIP_TRY(malloc_retry((void**)&c->d_M, bytes));
+    if ((sets & 2) && !c->d_Mold) HIP_TRY(malloc_retry((void**)&c->d_Mold, bytes));
+    if ((sets & 4) && !c->d_Mp) HIP_TRY(malloc_retry((void**)&c->d_Mp, bytes));
+    if ((sets & 8) && !c->d_work) HIP_TRY(malloc_retry((void**)&c->d_work, bytes));
     return EMME_OK;
 }
 
@@ -353,11 +364,11 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     const size_t bytes = node_cache_bytes(L.gk_points, nitems, c->cache_geom, -1);
     if (c->cache_bytes_used + (double)bytes > budget ||
         pool_alloc(&c->d_recs[cls], bytes, c->device) != hipSuccess ||
-        hipMalloc(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
+        malloc_retry(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
         (c->em_shared &&
-         hipMalloc(&c->d_wtab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess) ||
+         malloc_retry(&c->d_wtab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess) ||
         (!c->d_scale &&
-         hipMalloc((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
+         malloc_retry((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
         (void)hipGetLastError();
         pool_free(c->d_recs[cls], bytes, c->device);
         c->d_recs[cls] = nullptr;
@@ -505,13 +516,13 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (need > c->worklist_cap) {
             if (c->d_worklist) (void)hipFree(c->d_worklist);
             c->d_worklist = nullptr;
-            HIP_TRY(hipMalloc((void**)&c->d_worklist, need * sizeof(unsigned long long)));
+            HIP_TRY(malloc_retry((void**)&c->d_worklist, need * sizeof(unsigned long long)));
             if (c->d_defer_info) (void)hipFree(c->d_defer_info);
             c->d_defer_info = nullptr;
-            HIP_TRY(hipMalloc((void**)&c->d_defer_info, need * sizeof(unsigned long long)));
+            HIP_TRY(malloc_retry((void**)&c->d_defer_info, need * sizeof(unsigned long long)));
             c->worklist_cap = need;
         }
-        if (!c->d_worklist_count) HIP_TRY(hipMalloc((void**)&c->d_worklist_count, sizeof(unsigned int)));
+        if (!c->d_worklist_count) HIP_TRY(malloc_retry((void**)&c->d_worklist_count, sizeof(unsigned int)));
 
     }
     if (use_cache) {
@@ -673,8 +684,8 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
         emme_ctx_destroy(c);
         return code;
     };
-    if (hipMalloc((void**)&c->d_tab, tab.size() * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&c->d_pairs, pairs.size() * sizeof(ushort2)) != hipSuccess) {
+    if (malloc_retry((void**)&c->d_tab, tab.size() * sizeof(double)) != hipSuccess ||
+        malloc_retry((void**)&c->d_pairs, pairs.size() * sizeof(ushort2)) != hipSuccess) {
         set_error("hipMalloc failed for tables");
         return fail(EMME_ENOMEM);
     }
@@ -808,8 +819,8 @@ int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* 
     const size_t bytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
     double *dA = A, *dB = B;
     if (!devA) {
-        HIP_TRY(hipMalloc((void**)&dA, bytes));
-        if (hipMalloc((void**)&dB, bytes) != hipSuccess) {
+        HIP_TRY(malloc_retry((void**)&dA, bytes));
+        if (malloc_retry((void**)&dB, bytes) != hipSuccess) {
             (void)hipFree(dA);
             set_error("hipMalloc failed");
             return EMME_ENOMEM;
@@ -853,14 +864,14 @@ int emme_qr_secant_batch(emme_ctx_t* c, int n, int nbatch, const double* A, cons
         if (!devA && dA) (void)hipFree(dA);
         if (!devA && dB) (void)hipFree(dB);
     };
-    if (hipMalloc((void**)&dW, bytes) != hipSuccess) {
+    if (malloc_retry((void**)&dW, bytes) != hipSuccess) {
         set_error("hipMalloc failed");
         return EMME_ENOMEM;
     }
     if (devA) {
         dA = const_cast<double*>(A), dB = const_cast<double*>(B);
     } else {
-        if (hipMalloc((void**)&dA, bytes) != hipSuccess || hipMalloc((void**)&dB, bytes) != hipSuccess) {
+        if (malloc_retry((void**)&dA, bytes) != hipSuccess || malloc_retry((void**)&dB, bytes) != hipSuccess) {
             release();
             set_error("hipMalloc failed");
             return EMME_ENOMEM;
@@ -966,7 +977,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         if (need > c->iterates_cap) {
             if (c->d_iterates) (void)hipFree(c->d_iterates);
             c->d_iterates = nullptr;
-            HIP_TRY(hipMalloc((void**)&c->d_iterates, need * sizeof(double)));
+            HIP_TRY(malloc_retry((void**)&c->d_iterates, need * sizeof(double)));
             c->iterates_cap = need;
         }
         std::vector<double> nanv(need, std::numeric_limits<double>::quiet_NaN());
