@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
                 // bits 58..63: depth, bits 17..57: low path bits (diagnostics only; the list
                 // kernel masks them off), bits 32..47 would collide with b, so b sits at 17+24
                 A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
-                A.defer_info[slot] = ((unsigned long long)depth << 56) | (path & 0xffffffffffffffull);
+                A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)cls << 55) |
+                                     (path & 0x7fffffffffffffull);  // depth | contour class | path
                 deferred = true;
                 walking = false;
                 continue;
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
                     if (key[m] == cur) {
                         const unsigned int slot = atomicAdd(A.worklist_count, 1u);
                         A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)(item * 3 + m);
-                        A.defer_info[slot] = ((unsigned long long)depth << 56) | (path & 0xffffffffffffffull);
+                        A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)cls << 55) |
+                                     (path & 0x7fffffffffffffull);  // depth | contour class | path
                         deferred[m] = true;
                         key[m] = DONE;
                     }

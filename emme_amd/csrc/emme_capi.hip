@@ -383,62 +383,61 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         c->cache_depth = -2;
         return false;
     }
-    // run-time subtrees already registered (built for the other class): build them here too
-    for (int k = 1; k < c->cache_geom.nsub; ++k) {
-        const size_t eb = node_cache_bytes(L.gk_points, nitems, c->cache_geom, k - 1);
-        if (c->cache_bytes_used + (double)eb > budget) break;
-        if (pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
-            (void)hipGetLastError();
-            c->d_recs_ext[cls][k - 1] = nullptr;
-            break;
-        }
-        c->cache_bytes_used += (double)eb;
-        c->recs_ext_bytes[cls][k - 1] = eb;
-        (void)launch_node_cache(L, c->cache_geom, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1],
-                                c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->stream);
-    }
     return true;
 }
 
-// The previous cached fill deferred integrals because interval (depth, path) was not cached:
-// register a new subtree around it (root 4 levels up, 8 levels deep = 511 intervals) and
-// build it for the contour classes in use.  Failure is harmless: those integrals keep going
-// through the work list.
-void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned long long path,
-                       const bool need[2]) {
+// Which registered subtree covers interval (depth, path)?  -1 if none.
+int find_subtree(const NodeCacheGeom& g, int depth, unsigned long long path) {
+    for (int k = 0; k < g.nsub; ++k)
+        if (depth >= g.rd[k] && depth <= g.dd[k] && (path >> (depth - g.rd[k])) == g.rp[k]) return k;
+    return -1;
+}
+
+// The previous cached fill deferred integrals of contour class `cls` because interval
+// (depth, path) was not cached for that class: build the subtree that covers it for this class,
+// registering a new one around it (root 4 levels up, 8 levels deep = 511 intervals) if none does.
+// Subtrees are built per class, on demand: the few omegas on the other side of the imaginary
+// axis do not get 12 GB copies of regions they never visit.  Failure is harmless: those
+// integrals keep going through the work list.
+void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned long long path, int cls) {
     NodeCacheGeom& g = c->cache_geom;
-    if (g.nsub >= NODE_CACHE_MAX_SUB || c->ext_failed) return;
-    const int rd = depth - 4 < 1 ? 1 : depth - 4;
-    const int k = g.nsub;
-    g.rd[k] = rd;
-    g.rp[k] = path >> (depth - rd);
-    g.dd[k] = rd + 8;
-    g.nsub = k + 1;
+    if (c->ext_failed || !c->d_recs[cls]) return;
+    int k = find_subtree(g, depth, path);
+    const bool fresh = k < 0;
+    if (k == 0) return;  // the fixed subtree lives in the main buffer: nothing to add
+    if (fresh) {
+        if (g.nsub >= NODE_CACHE_MAX_SUB) return;
+        const int rd = depth - 4 < 1 ? 1 : depth - 4;
+        k = g.nsub;
+        g.rd[k] = rd;
+        g.rp[k] = path >> (depth - rd);
+        g.dd[k] = rd + 8;
+        g.nsub = k + 1;
+    } else if (c->d_recs_ext[cls][k - 1]) {
+        return;  // already there (the deferral was for an interval deeper than the subtree)
+    }
     const long nitems = cache_items(c);
     const double budget = c->cache_budget_gb * (double)(1 << 30);
     const size_t eb = node_cache_bytes(L.gk_points, nitems, g, k - 1);
-    bool any = false;
-    for (int cls = 0; cls < 2; ++cls) {
-        if (!need[cls] || !c->d_recs[cls]) continue;
-        if (c->cache_bytes_used + (double)eb > budget ||
-            pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
-            (void)hipGetLastError();
-            c->d_recs_ext[cls][k - 1] = nullptr;
-            c->ext_failed = true;
-            break;
-        }
-        c->cache_bytes_used += (double)eb;
-        c->recs_ext_bytes[cls][k - 1] = eb;
+    if (c->cache_bytes_used + (double)eb > budget ||
+        pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        c->d_recs_ext[cls][k - 1] = nullptr;
+        c->ext_failed = true;
+        if (fresh) g.nsub = k;  // nothing built: forget the registration
+        return;
+    }
+    c->cache_bytes_used += (double)eb;
+    c->recs_ext_bytes[cls][k - 1] = eb;
+    {
         ScopedSpan s(c, K_OTHER);
         if (launch_node_cache(L, g, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1], c->d_ttab[cls],
                               c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess)
             c->ext_failed = true;
-        any = true;
     }
-    if (!any) g.nsub = k;  // nothing built: forget the registration
     if (std::getenv("EMME_DEBUG"))
-        fprintf(stderr, "[emme] node cache: subtree %d added at depth %d path %llx (to depth %d), %.1f GiB in use\n",
-                k, rd, g.rp[k], g.dd[k], c->cache_bytes_used / (double)(1 << 30));
+        fprintf(stderr, "[emme] node cache: subtree %d (depth %d path %llx, to depth %d) built for class %d, %.1f GiB in use\n",
+                k, g.rd[k], g.rp[k], g.dd[k], cls, c->cache_bytes_used / (double)(1 << 30));
 }
 
 // host_active: which of the nbatch items to assemble (null = all).  Batches of wl_min or
@@ -492,21 +491,25 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (use_cache && c->d_worklist_count && c->d_defer_info) {
             HIP_TRY(hipMemcpyAsync(&c->last_deferred, c->d_worklist_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->last_deferred >= 32 && c->cache_geom.nsub < NODE_CACHE_MAX_SUB) {
+            if (c->last_deferred >= 32) {
                 const size_t cnt = std::min<size_t>(c->last_deferred, 1u << 16);
                 std::vector<unsigned long long> info(cnt);
                 HIP_TRY(hipMemcpy(info.data(), c->d_defer_info, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
                 std::sort(info.begin(), info.end());
-                unsigned long long best = 0;
-                size_t best_n = 0;
+                // most frequent missing interval per contour class (bit 55 of an entry)
+                unsigned long long best[2] = {0, 0};
+                size_t best_n[2] = {0, 0}, total[2] = {0, 0};
                 for (size_t q = 0; q < cnt;) {
                     size_t e = q;
                     while (e < cnt && info[e] == info[q]) ++e;
-                    if (e - q > best_n) best_n = e - q, best = info[q];
+                    const int k = (int)((info[q] >> 55) & 1ull);
+                    total[k] += e - q;
+                    if (e - q > best_n[k]) best_n[k] = e - q, best[k] = info[q];
                     q = e;
                 }
-                if (best_n * 4 >= cnt)
-                    add_cache_subtree(c, L, (int)(best >> 56), best & 0xffffffffffffffull, need);
+                for (int k = 0; k < 2; ++k)
+                    if (total[k] >= 32 && best_n[k] * 4 >= total[k])
+                        add_cache_subtree(c, L, (int)(best[k] >> 56), best[k] & 0x7fffffffffffffull, k);
             }
         }
     }
@@ -584,7 +587,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             if (!wl.empty() && c->d_defer_info) (void)hipMemcpy(dg.data(), c->d_defer_info, wl.size() * 8, hipMemcpyDeviceToHost);
             for (size_t q = 0; q < wl.size(); ++q)
                 fprintf(stderr, " b%llu:i%llu@d%llu:p%llx", wl[q] >> 32, wl[q] & 0xffffffffull, dg[q] >> 56,
-                        dg[q] & 0xffffffffffffffull);
+                        dg[q] & 0x7fffffffffffffull);
             fprintf(stderr, "\n");
         }
     } else if (n_act >= c->wl_min) {
