@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Cold-start cost of a context: creation, first root search (node-cache build), second one
+(development tool; the second context of the run shows the effect of the buffer pool)."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import emme_amd
 from oracle.binding import example_tokamak
 for n in (256, 512):
