@@ -48,6 +48,7 @@ struct AsmArgs {
     // electromagnetic fills with a shared cache: records are those of moment 0, indexed by pair;
     // moment m multiplies them by (c_nv W)^m with W from wtab (null = one record per moment)
     const double2* wtab[2];
+    int folded;  // cached records are in the folded form (exp(A0) inside the amplitudes)
 };
 
 // Value of the integrand at one quadrature node when a node-record cache may hold the
@@ -73,7 +74,6 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
                       : buf[(ci * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
                             lane_in_group];
         const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
-        d.A0 = mk(rec.A0.x, rec.A0.y);
         d.T = mk(tt.x, tt.y);
         d.Q1 = mk(rec.Q1.x, rec.Q1.y);
         d.Q0 = mk(rec.Q0.x, rec.Q0.y);
@@ -84,6 +84,19 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
             d.Q1 = d.Q1 * nv;
             d.Q0 = d.Q0 * nv;
         }
+        if (A.folded) {
+            // folded record: A0 = (|exp A0|^2, Re A0), amplitudes already carry exp(A0); here
+            // exp(T omega) is computed on the spot (no phase table in this kernel)
+            const cd arg = d.T * oc.omega;
+            if (!(rec.A0.y + arg.x >= -40.)) {
+                if (rec.A0.y + arg.x < -40.) return mk(0.0, 0.0);  // safe_exp clamp
+            }
+            double sa, ca;
+            fsincos(arg.y, sa, ca, tc);
+            const double ea = fexp(arg.x, tc);
+            return mk(ea * ca, ea * sa) * (oc.omega * d.Q1 + d.Q0);
+        }
+        d.A0 = mk(rec.A0.x, rec.A0.y);
     } else {
         d = node_data(x, A.P, pc, oc.omi, m);
     }
@@ -498,6 +511,7 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const No
     A.status = L.status;
     A.worklist = nullptr;
     A.worklist_count = nullptr;
+    A.folded = 0;
     A.geom = g ? make_geom(*g) : CacheGeom{};
     for (int c = 0; c < 2; ++c) {
         A.recs[c] = g ? (const NodeRec*)recs[c] : nullptr;
@@ -532,7 +546,7 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const unsigned int* count, const NodeCacheGeom* g,
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
-                                const void* const ttab[2], const void* const wtab[2],
+                                const void* const ttab[2], const void* const wtab[2], bool folded,
                                 hipStream_t stream) {
     AsmArgs A;
     A.P = L.P;
@@ -549,6 +563,7 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     A.status = L.status;
     A.worklist = worklist;
     A.worklist_count = count;
+    A.folded = folded ? 1 : 0;
     A.geom = g ? make_geom(*g) : CacheGeom{};
     for (int c = 0; c < 2; ++c) {
         A.recs[c] = g ? (const NodeRec*)recs[c] : nullptr;

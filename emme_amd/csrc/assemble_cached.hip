@@ -58,6 +58,7 @@ struct CacheArgs {
     double* scale;   // [NI] half-width (r - l)/2 of every cached interval
     int part;          // -1: main buffer (full tree + subtree 0); k >= 0: subtree k+1
     int first, count;  // global slot of the first interval and number of intervals filled
+    int folded;        // records in the FOLDED form (see NodeRec in node_cache.hpp)
 };
 
 template <int PTS>
@@ -93,9 +94,22 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
         const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
         const NodeData d = node_data(x, P, pc, A.omi, m);
         NodeRec rec;
-        rec.A0 = make_double2(d.A0.x, d.A0.y);
-        rec.Q1 = make_double2(d.Q1.x, d.Q1.y);
-        rec.Q0 = make_double2(d.Q0.x, d.Q0.y);
+        if (A.folded) {
+            // exp(A0) goes into the amplitudes once, here; what remains per (omega, node) is
+            // exp(T omega), which does not depend on the pair and comes from the phase table
+            double sa, ca;
+            sincos(d.A0.y, &sa, &ca);
+            const double ea = exp(fmin(d.A0.x, 700.0));
+            const cd ex = mk(ea * ca, ea * sa);
+            const cd q1 = ex * d.Q1, q0 = ex * d.Q0;
+            rec.A0 = make_double2(exp(fmin(2.0 * d.A0.x, 700.0)), d.A0.x);  // (|exp A0|^2, Re A0)
+            rec.Q1 = make_double2(q1.x, q1.y);
+            rec.Q0 = make_double2(q0.x, q0.y);
+        } else {
+            rec.A0 = make_double2(d.A0.x, d.A0.y);
+            rec.Q1 = make_double2(d.Q1.x, d.Q1.y);
+            rec.Q0 = make_double2(d.Q0.x, d.Q0.y);
+        }
         A.recs[w * GW + lane] = rec;
         if (item == 0) {
             A.ttab[(long)(A.first + idx) * GW + lane] = make_double2(d.T.x, d.T.y);
@@ -105,6 +119,41 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
             }
             if (lane == 0) A.scale[A.first + idx] = scale;
         }
+    }
+}
+
+// Phase table: E(interval, node, omega) = exp(T omega) for every cached interval and every omega
+// of a launch.  T = i t~ depends on the abscissa only, so this factor of the integrand is the same
+// for all N(N-1)/2 pairs: computed once per launch here (7 M complex exponentials for 128
+// omegas) instead of once per (pair, node, omega) in the fill (930 M).  Layout
+// [interval][node][omega position], so the omegas of a lane group read consecutive entries.
+struct PhaseArgs {
+    const double2* ttab[2];
+    const double2* omega;
+    const int* act_idx;
+    int n_act;
+    int nrows;  // cached intervals x GW
+    double2* etab;
+};
+__global__ __launch_bounds__(256) void k_phase_table(PhaseArgs A) {
+    const long total = (long)A.nrows * A.n_act;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / A.n_act;
+        const int w = (int)(e - row * A.n_act);
+        const double2 om = A.omega[A.act_idx[w]];
+        const int cls = -copysign(1.0, om.x) > 0.0 ? 0 : 1;
+        double2 ev = make_double2(0.0, 0.0);
+        if (A.ttab[cls]) {
+            const double2 t = A.ttab[cls][row];
+            const double ax = fma(t.x, om.x, -(t.y * om.y)), ay = fma(t.x, om.y, t.y * om.x);
+            if (ax <= 700.0) {  // beyond: not representable (and never met where the integrand lives)
+                double sa, ca;
+                sincos(ay, &sa, &ca);
+                const double ea = exp(ax);
+                ev = make_double2(ea * ca, ea * sa);
+            }
+        }
+        A.etab[e] = ev;
     }
 }
 
@@ -118,6 +167,7 @@ struct AsmCachedArgs {
     const NodeRec* recs_ext[2][NODE_CACHE_MAX_SUB - 1];  // run-time subtrees; null if absent
     const double2* ttab[2];   // [NI][GW] per class
     const double2* wtab[2];   // [NI][GW] per class: moment factor W (shared EM layout only)
+    const double2* etab;      // phase table of this launch (records are folded), or null
     const double* scale;      // [NI]
     unsigned long long* worklist;   // deferred integrals: batch << 32 | item
     unsigned long long* defer_info; // depth << 56 | path of the interval each entry was missing
@@ -138,11 +188,14 @@ struct AsmCachedArgs {
 #define EMME_CACHED_MIN_WAVES 3
 #endif
 
-template <int PTS>
+template <int PTS, bool FOLDED>
 __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(AsmCachedArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int H = (PTS + 1) / 2;
-    constexpr int NODE_UNROLL = PTS == 15 ? 5 : 3;  // trips of the 3-node loop unrolled
+#ifndef EMME_FOLDED_UNROLL
+#define EMME_FOLDED_UNROLL 5
+#endif
+    constexpr int NODE_UNROLL = PTS == 15 ? (FOLDED ? EMME_FOLDED_UNROLL : 5) : 3;  // trips of the 3-node loop unrolled
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     extern __shared__ double lds_raw[];  // eta | g | b
 
@@ -166,7 +219,8 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
     const int nsub = GW / n_eff;
     const int wslot = lane % n_eff, sub = lane / n_eff;
     const bool has_w = wslot < n_in_chunk;
-    const int b = has_w ? A.act_idx[chunk.x + wslot] : 0;
+    const int wpos = has_w ? chunk.x + wslot : 0;  // position in the launch's omega list
+    const int b = has_w ? A.act_idx[wpos] : 0;
     cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
     if (has_w) {
         omega = mk(A.omega[b].x, A.omega[b].y);
@@ -255,17 +309,31 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
             const NodeRec* rp =
                 which < 0 ? recs + ((long)item * NI_MAIN + cslot) * GW
                           : ebuf + ((long)item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW;
-            const double2* tp = ttab + (long)cslot * GW;
+            // per node: T (shared by all omegas) or, folded, this omega's exp(T omega)
+            const double2* tp = FOLDED ? A.etab + (long)cslot * GW * A.n_act + wpos : ttab + (long)cslot * GW;
+            const int tstride = FOLDED ? A.n_act : 1;
             cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
             // visiting order s = 0..PTS-1: centre, +x_1, -x_1, +x_2, -x_2, ...
             auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
             auto proc = [&](const NodeRec& rec, const double2 tt, int s) {
-                NodeData d;
-                d.A0 = mk(rec.A0.x, rec.A0.y);
-                d.T = mk(tt.x, tt.y);
-                d.Q1 = mk(rec.Q1.x, rec.Q1.y);
-                d.Q0 = mk(rec.Q0.x, rec.Q0.y);
-                const cd f = node_eval(d, omega, TC);
+                cd f;
+                if (FOLDED) {
+                    // folded record (|exp A0|^2, Re A0, exp(A0) Q1, exp(A0) Q0) and tt = exp(T omega)
+                    // from the phase table: safe_exp clamp (src/Parameters.cpp:167-173) as
+                    // |exp(A0 + T omega)|^2 < exp(-80), then F = E (omega Q1 + Q0)
+                    const bool clamped = fma(tt.x, tt.x, tt.y * tt.y) * rec.A0.x < 1.8048513878454153e-35;
+                    const cd S = mk(fma(omega.x, rec.Q1.x, fma(-omega.y, rec.Q1.y, rec.Q0.x)),
+                                    fma(omega.x, rec.Q1.y, fma(omega.y, rec.Q1.x, rec.Q0.y)));
+                    const cd ef = mk(tt.x, tt.y) * S;
+                    f = clamped ? mk(0.0, 0.0) : ef;
+                } else {
+                    NodeData d;
+                    d.A0 = mk(rec.A0.x, rec.A0.y);
+                    d.T = mk(tt.x, tt.y);
+                    d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+                    d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+                    f = node_eval(d, omega, TC);
+                }
                 if (s & 1) {
                     fplus = f;
                 } else {
@@ -279,14 +347,14 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
             // while a third record is being evaluated; for GK15 the loop is fully unrolled (node
             // order and record offsets become immediates: ~10 % faster; GK31 would spill)
             NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
-            double2 t0 = tp[node_of(0)], t1 = tp[node_of(1)], t2;
+            double2 t0 = tp[node_of(0) * tstride], t1 = tp[node_of(1) * tstride], t2;
 #pragma unroll NODE_UNROLL
             for (int s = 0; s < PTS; s += 3) {
-                if (s + 2 < PTS) r2 = rp[node_of(s + 2)], t2 = tp[node_of(s + 2)];
+                if (s + 2 < PTS) r2 = rp[node_of(s + 2)], t2 = tp[node_of(s + 2) * tstride];
                 proc(r0, t0, s);
-                if (s + 3 < PTS) r0 = rp[node_of(s + 3)], t0 = tp[node_of(s + 3)];
+                if (s + 3 < PTS) r0 = rp[node_of(s + 3)], t0 = tp[node_of(s + 3) * tstride];
                 if (s + 1 < PTS) proc(r1, t1, s + 1);
-                if (s + 4 < PTS) r1 = rp[node_of(s + 4)], t1 = tp[node_of(s + 4)];
+                if (s + 4 < PTS) r1 = rp[node_of(s + 4)], t1 = tp[node_of(s + 4) * tstride];
                 if (s + 2 < PTS) proc(r2, t2, s + 2);
             }
             ++item_intervals;
@@ -359,7 +427,7 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
 // The walk order is the pre-order of the union: every moment holds the key of the next interval
 // it needs, key = position of the left end (path << (56 - depth)) * 64 + depth, and the lane
 // always takes the smallest key.  ~2.9x fewer intervals and record loads than three separate walks.
-template <int PTS>
+template <int PTS, bool FOLDED>
 __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int H = (PTS + 1) / 2;
@@ -388,7 +456,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     const int nsub = GW / n_eff;
     const int wslot = lane % n_eff, sub = lane / n_eff;
     const bool has_w = wslot < n_in_chunk;
-    const int b = has_w ? A.act_idx[chunk.x + wslot] : 0;
+    const int wpos = has_w ? chunk.x + wslot : 0;  // position in the launch's omega list
+    const int b = has_w ? A.act_idx[wpos] : 0;
     cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
     if (has_w) {
         omega = mk(A.omega[b].x, A.omega[b].y);
@@ -484,7 +553,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
             const NodeRec* rp =
                 which < 0 ? recs + ((long)item * NI_MAIN + cslot) * GW
                           : ebuf + ((long)item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW;
-            const double2* tp = ttab + off;
+            const double2* tp = FOLDED ? A.etab + off * A.n_act + wpos : ttab + off;
+            const int tstride = FOLDED ? A.n_act : 1;
             const double2* wp = wtab + off;
             cd K[3], G[3], fplus[3];
 #pragma unroll
@@ -493,13 +563,21 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
             // summation order, include/functions.h:186-201)
             auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
             auto proc = [&](const NodeRec& rec, const double2 tt, const double2 ww, int s) {
-                NodeData d;
-                d.A0 = mk(rec.A0.x, rec.A0.y);
-                d.T = mk(tt.x, tt.y);
-                d.Q1 = mk(rec.Q1.x, rec.Q1.y);
-                d.Q0 = mk(rec.Q0.x, rec.Q0.y);
                 cd f[3];
-                f[0] = node_eval(d, omega, TC);
+                if (FOLDED) {
+                    const bool clamped = fma(tt.x, tt.x, tt.y * tt.y) * rec.A0.x < 1.8048513878454153e-35;
+                    const cd S = mk(fma(omega.x, rec.Q1.x, fma(-omega.y, rec.Q1.y, rec.Q0.x)),
+                                    fma(omega.x, rec.Q1.y, fma(omega.y, rec.Q1.x, rec.Q0.y)));
+                    const cd ef = mk(tt.x, tt.y) * S;
+                    f[0] = clamped ? mk(0.0, 0.0) : ef;
+                } else {
+                    NodeData d;
+                    d.A0 = mk(rec.A0.x, rec.A0.y);
+                    d.T = mk(tt.x, tt.y);
+                    d.Q1 = mk(rec.Q1.x, rec.Q1.y);
+                    d.Q0 = mk(rec.Q0.x, rec.Q0.y);
+                    f[0] = node_eval(d, omega, TC);
+                }
                 const cd nv = c_nv * mk(ww.x, ww.y);
                 f[1] = f[0] * nv;
                 f[2] = f[1] * nv;
@@ -517,15 +595,15 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
             };
             // two record loads in flight while a third record is being evaluated
             NodeRec r0 = rp[node_of(0)], r1 = rp[node_of(1)], r2;
-            double2 t0 = tp[node_of(0)], t1 = tp[node_of(1)], t2;
+            double2 t0 = tp[node_of(0) * tstride], t1 = tp[node_of(1) * tstride], t2;
             double2 w0 = wp[node_of(0)], w1 = wp[node_of(1)], w2;
 #pragma unroll NODE_UNROLL
             for (int s = 0; s < PTS; s += 3) {
-                if (s + 2 < PTS) r2 = rp[node_of(s + 2)], t2 = tp[node_of(s + 2)], w2 = wp[node_of(s + 2)];
+                if (s + 2 < PTS) r2 = rp[node_of(s + 2)], t2 = tp[node_of(s + 2) * tstride], w2 = wp[node_of(s + 2)];
                 proc(r0, t0, w0, s);
-                if (s + 3 < PTS) r0 = rp[node_of(s + 3)], t0 = tp[node_of(s + 3)], w0 = wp[node_of(s + 3)];
+                if (s + 3 < PTS) r0 = rp[node_of(s + 3)], t0 = tp[node_of(s + 3) * tstride], w0 = wp[node_of(s + 3)];
                 if (s + 1 < PTS) proc(r1, t1, w1, s + 1);
-                if (s + 4 < PTS) r1 = rp[node_of(s + 4)], t1 = tp[node_of(s + 4)], w1 = wp[node_of(s + 4)];
+                if (s + 4 < PTS) r1 = rp[node_of(s + 4)], t1 = tp[node_of(s + 4) * tstride], w1 = wp[node_of(s + 4)];
                 if (s + 2 < PTS) proc(r2, t2, w2, s + 2);
             }
             // per moment: include/functions.h:203-208, 231-247
@@ -609,7 +687,8 @@ size_t node_ttab_bytes(int gk_points, int max_intervals) {
 }
 
 hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
-                             void* recs, void* ttab, void* wtab, double* scale, hipStream_t stream) {
+                             void* recs, void* ttab, void* wtab, double* scale, bool folded,
+                             hipStream_t stream) {
     CacheArgs A;
     A.P = L.P;
     A.tab = L.tab;
@@ -621,6 +700,7 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, in
     A.ttab = (double2*)ttab;
     A.wtab = (double2*)wtab;
     A.scale = scale;
+    A.folded = folded ? 1 : 0;
     A.part = part;
     A.first = part < 0 ? 0 : A.geom.base[part + 1];
     A.count = part < 0 ? A.geom.ni_main() : A.geom.ni_sub(part + 1);
@@ -636,7 +716,7 @@ hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, in
 hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& g,
                                   const void* const recs[2],
                                   const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
-                                  const void* const ttab[2], const double* scale,
+                                  const void* const ttab[2], const double* scale, const void* etab,
                                   unsigned long long* worklist, unsigned int* worklist_count,
                                   unsigned long long* defer_info, const int* act_idx, int n_act,
                                   const void* chunks, int nchunks, hipStream_t stream) {
@@ -654,6 +734,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
         A.wtab[c] = nullptr;
     }
     A.scale = scale;
+    A.etab = (const double2*)etab;
     A.worklist = worklist;
     A.worklist_count = worklist_count;
     A.defer_info = defer_info;
@@ -675,10 +756,14 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)nchunks), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
-    if (L.gk_points == 15)
-        hipLaunchKernelGGL(k_assemble_cached<15>, grid, block, lds, stream, A);
+    if (L.gk_points == 15 && etab)
+        hipLaunchKernelGGL((k_assemble_cached<15, true>), grid, block, lds, stream, A);
+    else if (L.gk_points == 15)
+        hipLaunchKernelGGL((k_assemble_cached<15, false>), grid, block, lds, stream, A);
+    else if (etab)
+        hipLaunchKernelGGL((k_assemble_cached<31, true>), grid, block, lds, stream, A);
     else
-        hipLaunchKernelGGL(k_assemble_cached<31>, grid, block, lds, stream, A);
+        hipLaunchKernelGGL((k_assemble_cached<31, false>), grid, block, lds, stream, A);
     return hipGetLastError();
 }
 
@@ -686,7 +771,7 @@ hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeo
                                   const void* const recs[2],
                                   const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                   const void* const ttab[2], const void* const wtab[2], const double* scale,
-                                  unsigned long long* worklist, unsigned int* worklist_count,
+                                  const void* etab, unsigned long long* worklist, unsigned int* worklist_count,
                                   unsigned long long* defer_info, const int* act_idx, int n_act,
                                   const void* chunks, int nchunks, hipStream_t stream) {
     AsmCachedArgs A;
@@ -703,6 +788,7 @@ hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeo
         A.wtab[c] = (const double2*)wtab[c];
     }
     A.scale = scale;
+    A.etab = (const double2*)etab;
     A.worklist = worklist;
     A.worklist_count = worklist_count;
     A.defer_info = defer_info;
@@ -724,10 +810,32 @@ hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeo
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)nchunks), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
-    if (L.gk_points == 15)
-        hipLaunchKernelGGL(k_assemble_cached_em<15>, grid, block, lds, stream, A);
+    if (L.gk_points == 15 && etab)
+        hipLaunchKernelGGL((k_assemble_cached_em<15, true>), grid, block, lds, stream, A);
+    else if (L.gk_points == 15)
+        hipLaunchKernelGGL((k_assemble_cached_em<15, false>), grid, block, lds, stream, A);
+    else if (etab)
+        hipLaunchKernelGGL((k_assemble_cached_em<31, true>), grid, block, lds, stream, A);
     else
-        hipLaunchKernelGGL(k_assemble_cached_em<31>, grid, block, lds, stream, A);
+        hipLaunchKernelGGL((k_assemble_cached_em<31, false>), grid, block, lds, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_phase_table(int gk_points, int n_intervals, const void* const ttab[2],
+                              const double* omega, const int* act_idx, int n_act, void* etab,
+                              hipStream_t stream) {
+    PhaseArgs A;
+    A.ttab[0] = (const double2*)ttab[0], A.ttab[1] = (const double2*)ttab[1];
+    A.omega = (const double2*)omega;
+    A.act_idx = act_idx;
+    A.n_act = n_act;
+    A.nrows = n_intervals * (gk_points == 15 ? 16 : 32);
+    A.etab = (double2*)etab;
+    const long total = (long)A.nrows * n_act;
+    long blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_phase_table, dim3((unsigned)blocks), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 

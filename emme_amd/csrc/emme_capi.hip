@@ -84,6 +84,9 @@ struct emme_ctx {
     void* d_ttab[2] = {nullptr, nullptr};      // T table per class
     void* d_wtab[2] = {nullptr, nullptr};      // moment-factor table per class (shared EM layout)
     bool em_shared = false;    // nm == 3: one record per (pair, interval, node), three moments per lane
+    bool folded = true;        // records carry exp(A0); exp(T omega) comes from a per-launch phase table
+    void* d_etab = nullptr;    // phase table of the current launch
+    size_t etab_bytes = 0;
     bool ext_failed = false;
     unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
     double cache_bytes_used = 0.0;
@@ -379,7 +382,7 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     c->recs_bytes[cls] = bytes;
     ScopedSpan s(c, K_OTHER);
     if (launch_node_cache(L, c->cache_geom, -1, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_ttab[cls],
-                          c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess) {
+                          c->d_wtab[cls], c->d_scale, c->folded, c->stream) != hipSuccess) {
         c->cache_depth = -2;
         return false;
     }
@@ -432,7 +435,7 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
     {
         ScopedSpan s(c, K_OTHER);
         if (launch_node_cache(L, g, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1], c->d_ttab[cls],
-                              c->d_wtab[cls], c->d_scale, c->stream) != hipSuccess)
+                              c->d_wtab[cls], c->d_scale, c->folded, c->stream) != hipSuccess)
             c->ext_failed = true;
     }
     if (std::getenv("EMME_DEBUG"))
@@ -560,21 +563,36 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
         c->last_fill_mode = 2;
+        if (n_lane && c->folded) {
+            // phase table of this launch: exp(T omega) for every cached interval, node and omega
+            const int n_int = node_cache_intervals(c->cache_geom);
+            const size_t need = (size_t)n_lane * n_int * gw * 2 * sizeof(double);
+            if (need > c->etab_bytes) {
+                if (c->d_etab) (void)hipFree(c->d_etab);
+                c->d_etab = nullptr, c->etab_bytes = 0;
+                HIP_TRY(malloc_retry(&c->d_etab, need + need / 4));
+                c->etab_bytes = need + need / 4;
+            }
+            ScopedSpan s(c, K_OTHER);
+            HIP_TRY(launch_phase_table(L.gk_points, n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_etab,
+                                       c->stream));
+        }
         if (n_lane) {
             ScopedSpan s(c, K_ASM);
+            const void* etab = c->folded ? c->d_etab : nullptr;
             if (c->em_shared)
                 HIP_TRY(launch_assemble_cached_em(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_wtab,
-                                                  c->d_scale, c->d_worklist, c->d_worklist_count, c->d_defer_info,
+                                                  c->d_scale, etab, c->d_worklist, c->d_worklist_count, c->d_defer_info,
                                                   c->d_actidx, n_lane, c->d_chunks, nchunks, c->stream));
             else
-                HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale,
+                HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale, etab,
                                                c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx,
                                                n_lane, c->d_chunks, nchunks, c->stream));
         }
         if (n_lane) {
             ScopedSpan s(c, K_DEFER);
             HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
-                                         c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->stream));
+                                         c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream));
         }
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
@@ -655,6 +673,8 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     // electromagnetic contexts share one node record per (pair, interval, node) between the three
     // moments (EMME_EM_SHARED=0: one record per moment, for A/B comparisons)
     c->em_shared = !es && !(std::getenv("EMME_EM_SHARED") && std::atoi(std::getenv("EMME_EM_SHARED")) == 0);
+    // EMME_PHASE_TABLE=0: unfolded records and exp(A0 + T omega) per (pair, node, omega) in the fill
+    c->folded = !(std::getenv("EMME_PHASE_TABLE") && std::atoi(std::getenv("EMME_PHASE_TABLE")) == 0);
 
     DevParams& P = c->P;
     std::vector<double> tab(3 * (size_t)N);
@@ -721,6 +741,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         for (int e = 0; e < NODE_CACHE_MAX_SUB - 1; ++e) pool_free(c->d_recs_ext[k][e], c->recs_ext_bytes[k][e], c->device);
     }
     F(c->d_scale);
+    F(c->d_etab);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);

@@ -52,13 +52,14 @@ int node_cache_intervals(const NodeCacheGeom& g);
 // wtab != null: electromagnetic SHARED layout -- one record per (pair, interval, node), that of
 // moment 0, plus the table of moment factors W (see emme_device.hpp::node_w)
 hipError_t launch_node_cache(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
-                             void* recs, void* ttab, void* wtab, double* scale, hipStream_t stream);
+                             void* recs, void* ttab, void* wtab, double* scale, bool folded,
+                             hipStream_t stream);
 // electromagnetic fill on the shared layout: a lane walks the three moments of a pair together
 hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeom& g,
                                      const void* const recs[2],
                                      const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                      const void* const ttab[2], const void* const wtab[2],
-                                     const double* scale, unsigned long long* worklist,
+                                     const double* scale, const void* etab, unsigned long long* worklist,
                                      unsigned int* worklist_count, unsigned long long* defer_info,
                                      const int* act_idx, int n_act, const void* chunks, int nchunks,
                                      hipStream_t stream);
@@ -66,16 +67,22 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
                                   const void* const recs[2],
                                   const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                   const void* const ttab[2], const double* scale,
+                                  const void* etab /*phase table of this launch, or null*/,
                                   unsigned long long* worklist, unsigned int* worklist_count,
                                   unsigned long long* defer_info, const int* act_idx, int n_act,
                                   const void* chunks /*int2[nchunks]: (first, size)*/, int nchunks,
                                   hipStream_t stream);
+// exp(T omega) for every cached interval/node and the n_act omegas of a launch: etab is
+// [n_intervals][GW][n_act] complex (the records must be in the folded form)
+hipError_t launch_phase_table(int gk_points, int n_intervals, const void* const ttab[2],
+                              const double* omega, const int* act_idx, int n_act, void* etab,
+                              hipStream_t stream);
 // integrals deferred by the cached kernels, recomputed by k_assemble_coop (a workgroup each)
 hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long long* worklist,
                                 const unsigned int* count, const NodeCacheGeom* g,
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
-                                const void* const ttab[2], const void* const wtab[2],
+                                const void* const ttab[2], const void* const wtab[2], bool folded,
                                 hipStream_t stream);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
