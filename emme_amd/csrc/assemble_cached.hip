@@ -23,6 +23,8 @@
 //     record per node and one walk over the union of their trees.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "assemble_common.hpp"
 #include "launch.hpp"
 #include "node_cache.hpp"
@@ -672,6 +674,218 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     }
 }
 
+// ---- union walk on folded records + phase table (electrostatic, GK15) ------------------------------
+// The independent-lane kernel above issues 60 loads per lane and interval at per-lane addresses
+// (a wave-level load touches ~21 L1 lines): once the phase table has taken the transcendental
+// work away, that memory-pipeline work is what bounds it.  Here the 16 lanes of a group stay on
+// ONE interval at a time -- the union of their omegas' trees in pre-order, like k_assemble_wl --
+//   phase 1  lane = node : one coalesced load of the interval's 16 records (768 B) into LDS;
+//   phase 2  lane = omega: every lane whose own tree contains the interval walks the 15 nodes,
+//            records broadcast from LDS, exp(T omega) from the phase table (16 consecutive
+//            entries per node for the group), ~10 flops per node; own Kronrod/Gauss sums, own
+//            abs_tol, own accept/split decision (the reference's, omega by omega).
+// Lanes whose tree does not contain the interval sit the round out (cheap now: a round is
+// mostly memory).  Each lane holds the pre-order key of the next interval it needs; the group
+// takes the minimum (DPP row reduction).  Intervals outside the cache defer the integrals that
+// need them to the cooperative kernel.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_step_u64(unsigned long long x) {
+    const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < x ? o : x;
+}
+__device__ __forceinline__ unsigned long long row16_min_u64(unsigned long long v) {
+    v = dpp_min_step_u64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_min_step_u64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_min_step_u64<0x141>(v);  // row_half_mirror
+    v = dpp_min_step_u64<0x140>(v);  // row_mirror
+    return v;
+}
+
+template <int PTS>
+__global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
+    static_assert(PTS == 15, "lane groups of 16: GK15");
+    constexpr int GW = 16;
+    constexpr int H = (PTS + 1) / 2;
+    constexpr int GROUPS_PER_BLOCK = 256 / GW;
+    constexpr int KD = 56;
+    extern __shared__ double lds_raw[];  // eta | g | b | scale table | per-group record slots
+
+    const DevParams& P = A.P;
+    const int N = P.N, dim = P.dim;
+    for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_raw[k] = A.tab[k];
+    const int NI = A.geom.ni();
+    for (int k = threadIdx.x; k < NI; k += blockDim.x) lds_raw[3 * N + k] = A.scale[k];
+    __syncthreads();
+    const double* eta = lds_raw;
+    const double* gtab = lds_raw + N;
+    const double* scale_tab = lds_raw + 3 * N;
+    const int group_in_block = threadIdx.x / GW;
+    const int lane = threadIdx.x % GW;
+    double2* slots = reinterpret_cast<double2*>(lds_raw + 3 * N + NI + ((3 * N + NI) & 1)) + group_in_block * (GW * 3);
+
+    const int2 chunk = A.chunks[blockIdx.y];
+    const bool has_w = lane < chunk.y;
+    const int wpos = has_w ? chunk.x + lane : 0;
+    const int b = has_w ? A.act_idx[wpos] : 0;
+    cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
+    if (has_w) {
+        omega = mk(A.omega[b].x, A.omega[b].y);
+        if (A.Mold) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
+    }
+    const int cls = -copysign(1.0, omega.x) > 0.0 ? 0 : 1;
+    double2* Mb = A.M + (size_t)b * dim * dim;
+    const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
+    double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
+    auto store = [&](int r, int c, cd v) {
+        const size_t idx = (size_t)r * dim + c;
+        Mb[idx] = make_double2(v.x, v.y);
+        if (Moldb) {
+            const double2 o = Moldb[idx];
+            const cd d = (v - mk(o.x, o.y)) * rdw;
+            Mpb[idx] = make_double2(d.x, d.y);
+        }
+    };
+    if (blockIdx.x == 0 && has_w)  // diagonal (include/solver.h:442-443)
+        for (int i = group_in_block; i < N; i += GROUPS_PER_BLOCK) store(i, i, mk(P.diag_a, 0.0));
+
+    const double* WK = kWk15;
+    const double* WG = kWg15;
+    const double inv_scale = 2. / (M_PI / 2.0);
+    const int nitems = A.npairs;
+    const int ngroups = gridDim.x * GROUPS_PER_BLOCK;
+    auto make_key = [](int depth, unsigned long long path) -> unsigned long long {
+        return ((path << (KD - depth)) << 6) | (unsigned long long)depth;
+    };
+    const unsigned long long DONE = ~0ull;
+    unsigned long long my_intervals = 0;
+    int bad = 0;
+    for (int item = blockIdx.x * GROUPS_PER_BLOCK + group_in_block; item < nitems; item += ngroups) {
+        const ushort2 ij = A.pairs[item];
+        const int i = ij.x, j = ij.y;
+        unsigned long long key = has_w ? 0ull : DONE;  // root: depth 0, path 0
+        double abs_tol = 0.0;
+        cd sum = mk(0.0, 0.0);
+        int count = 0;
+        bool deferred = false;
+        for (;;) {
+            // next interval of the union; a group whose omegas sit on both sides of the imaginary
+            // axis walks contour class 0 first (bit 63 of the group key), the records differ
+            const unsigned long long mykey = key == DONE ? DONE : (key | ((unsigned long long)cls << 63));
+            const unsigned long long curk = row16_min_u64(mykey);
+            if (curk == DONE) break;  // group-uniform
+            const int ccls = (int)(curk >> 63);
+            const unsigned long long cur = curk & ~(1ull << 63);
+            const int depth = (int)(cur & 63ull);
+            const unsigned long long path = (cur >> 6) >> (KD - depth);
+            const bool mine = key == cur && cls == ccls;
+            int which;
+            const int cslot = A.geom.slot(depth, path, which);
+            const NodeRec* ebuf = which >= 0 ? A.recs_ext[ccls][which] : A.recs[ccls];
+            if (cslot < 0 || ebuf == nullptr) {
+                if (mine) {  // outside the cache: this omega's integral goes to the cooperative kernel
+                    const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+                    A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
+                    A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)cls << 55) |
+                                         (path & 0x7fffffffffffffull);
+                    deferred = true;
+                    key = DONE;
+                }
+                continue;
+            }
+            // ---- phase 1: lane = node, one coalesced 768-byte read ------------------------------
+            {
+                const NodeRec* rp =
+                    which < 0 ? ebuf + ((long)item * A.geom.ni_main() + cslot) * GW
+                              : ebuf + ((long)item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW;
+                const NodeRec rec = rp[lane];
+                double2* s = slots + lane * 3;
+                s[0] = rec.A0, s[1] = rec.Q1, s[2] = rec.Q0;
+            }
+            // the slots are produced and consumed inside one wave: LDS operations of a wave
+            // complete in issue order; the fences keep the compiler from moving them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- phase 2: lane = omega -----------------------------------------------------------
+            if (mine) {
+                const double2* tp = A.etab + (long)cslot * GW * A.n_act + wpos;
+                auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
+                double2 ev[PTS];
+#pragma unroll
+                for (int s = 0; s < PTS; ++s) ev[s] = tp[(long)node_of(s) * A.n_act];
+                cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
+#pragma unroll
+                for (int s = 0; s < PTS; ++s) {
+                    const double2* r = slots + node_of(s) * 3;
+                    const double2 a0 = r[0], q1 = r[1], q0 = r[2];
+                    const double2 tt = ev[s];
+                    // safe_exp clamp (src/Parameters.cpp:167-173) as |exp(A0 + T omega)|^2 < exp(-80)
+                    const bool clamped = fma(tt.x, tt.x, tt.y * tt.y) * a0.x < 1.8048513878454153e-35;
+                    const cd S = mk(fma(omega.x, q1.x, fma(-omega.y, q1.y, q0.x)),
+                                    fma(omega.x, q1.y, fma(omega.y, q1.x, q0.y)));
+                    const cd ef = mk(tt.x, tt.y) * S;
+                    const cd f = clamped ? mk(0.0, 0.0) : ef;
+                    if (s & 1) {
+                        fplus = f;
+                    } else {
+                        const int q = s >> 1;
+                        const cd fs = s == 0 ? f : fplus + f;
+                        K = K + WK[q] * fs;
+                        if ((q & 1) == 0) G = G + WG[q >> 1] * fs;
+                    }
+                }
+                ++count;
+                // include/functions.h:203-208, 231-247
+                const double scale = scale_tab[cslot];
+                const double dKx = K.x - G.x, dKy = K.y - G.y;
+                const double absK = sqrt(fma(K.x, K.x, K.y * K.y));
+                double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
+                const cd integral = mk(K.x * scale, K.y * scale);
+                err *= scale;
+                const double rel_abs = P.rel_tol * (absK * scale);
+                if (abs_tol == 0.0) abs_tol = rel_abs;
+                bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
+                             err > rel_abs + P.prec_goal;
+                if (split && (depth >= KD || count >= (1 << 18))) {
+                    split = false;
+                    bad = 1;
+                }
+                if (split) {
+                    key = make_key(depth + 1, path << 1);
+                } else {
+                    sum = sum + integral;
+                    unsigned long long p2 = path + 1;
+                    const int tz = min(depth, (int)__builtin_ctzll(p2 | (1ull << 63)));
+                    p2 >>= tz;
+                    const int d2 = depth - tz;
+                    key = d2 == 0 ? DONE : make_key(d2, p2);
+                }
+            }
+            // phase-2 reads are done before the next round overwrites the slots
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (has_w && !deferred) {
+            my_intervals += (unsigned long long)count;
+            const double dg = gtab[i] - gtab[j], de = eta[i] - eta[j];
+            cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));  // -i pref sum, Parameters.cpp:182
+            if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+            kap = kap + kappa_e(0, P, de, dg, omega);
+            const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
+            store(i, j, v);
+            store(j, i, v);
+        }
+    }
+    if (has_w) {
+        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
+        if (bad) A.status[b] = 1;
+    }
+}
+
 }  // namespace
 
 // part -1 = main buffer (full tree + subtree 0), part k >= 0 = run-time subtree k+1
@@ -756,7 +970,17 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)nchunks), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
-    if (L.gk_points == 15 && etab)
+    // electrostatic GK15 on folded records: the union-walk kernel (EMME_UNION=0: independent lanes)
+    static const bool union_walk = !(std::getenv("EMME_UNION") && atoi(std::getenv("EMME_UNION")) == 0);
+    if (L.gk_points == 15 && etab && union_walk && L.P.nm == 1) {
+        const long ug = (nitems + L.items_per_group - 1) / L.items_per_group;
+        long ugx = (ug + 15) / 16;
+        if (ugx < 1) ugx = 1;
+        if (ugx > 65535) ugx = 65535;
+        const size_t n0 = (size_t)3 * L.P.N + (size_t)A.geom.ni();
+        const size_t ulds = (n0 + (n0 & 1)) * sizeof(double) + (size_t)16 * 16 * 3 * sizeof(double2);
+        hipLaunchKernelGGL((k_assemble_union<15>), dim3((unsigned)ugx, (unsigned)nchunks), block, ulds, stream, A);
+    } else if (L.gk_points == 15 && etab)
         hipLaunchKernelGGL((k_assemble_cached<15, true>), grid, block, lds, stream, A);
     else if (L.gk_points == 15)
         hipLaunchKernelGGL((k_assemble_cached<15, false>), grid, block, lds, stream, A);
