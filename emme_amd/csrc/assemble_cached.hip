@@ -711,20 +711,17 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
     constexpr int H = (PTS + 1) / 2;
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     constexpr int KD = 56;
-    extern __shared__ double lds_raw[];  // eta | g | b | scale table | per-group record slots
+    extern __shared__ double lds_raw[];  // eta | g | b | per-group record slots
 
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
     for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_raw[k] = A.tab[k];
-    const int NI = A.geom.ni();
-    for (int k = threadIdx.x; k < NI; k += blockDim.x) lds_raw[3 * N + k] = A.scale[k];
     __syncthreads();
     const double* eta = lds_raw;
     const double* gtab = lds_raw + N;
-    const double* scale_tab = lds_raw + 3 * N;
     const int group_in_block = threadIdx.x / GW;
     const int lane = threadIdx.x % GW;
-    double2* slots = reinterpret_cast<double2*>(lds_raw + 3 * N + NI + ((3 * N + NI) & 1)) + group_in_block * (GW * 3);
+    double2* slots = reinterpret_cast<double2*>(lds_raw + 3 * N + ((3 * N) & 1)) + group_in_block * (GW * 3);
 
     const int2 chunk = A.chunks[blockIdx.y];
     const bool has_w = lane < chunk.y;
@@ -839,7 +836,7 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
                 }
                 ++count;
                 // include/functions.h:203-208, 231-247
-                const double scale = scale_tab[cslot];
+                const double scale = A.scale[cslot];  // (r - l)/2 of the interval: small table, L2-resident
                 const double dKx = K.x - G.x, dKy = K.y - G.y;
                 const double absK = sqrt(fma(K.x, K.x, K.y * K.y));
                 double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
@@ -977,7 +974,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
         long ugx = (ug + 15) / 16;
         if (ugx < 1) ugx = 1;
         if (ugx > 65535) ugx = 65535;
-        const size_t n0 = (size_t)3 * L.P.N + (size_t)A.geom.ni();
+        const size_t n0 = (size_t)3 * L.P.N;
         const size_t ulds = (n0 + (n0 & 1)) * sizeof(double) + (size_t)16 * 16 * 3 * sizeof(double2);
         hipLaunchKernelGGL((k_assemble_union<15>), dim3((unsigned)ugx, (unsigned)nchunks), block, ulds, stream, A);
     } else if (L.gk_points == 15 && etab)
