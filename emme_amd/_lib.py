@@ -246,7 +246,8 @@ class Context:
         _check(self.lib.emme_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
 
     FILL_KERNELS = {0: "k_assemble (lanes=nodes)", 1: "k_assemble_wl (omega-lane)",
-                    2: "k_assemble_cached (HBM node cache)"}
+                    2: "k_assemble_cached (HBM node cache)",
+                    3: "k_assemble_union (HBM node cache + phase table)"}
 
     def fill_kernel(self) -> str:
         return self.FILL_KERNELS.get(self.lib.emme_ctx_fill_mode(self.h), "none yet")

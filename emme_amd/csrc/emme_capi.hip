@@ -567,7 +567,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_lane, hipMemcpyHostToDevice, c->stream));
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
-        c->last_fill_mode = 2;
+        c->last_fill_mode = union_walk ? 3 : 2;
         if (n_lane && c->folded) {
             // phase table of this launch: exp(T omega) for every cached interval, node and omega
             const int n_int = node_cache_intervals(c->cache_geom);

@@ -89,7 +89,8 @@ void emme_release_pooled_memory(void);
 /* Launch everything on this hipStream_t (e.g. torch's current stream). NULL = default. */
 int emme_ctx_set_stream(emme_ctx_t* ctx, void* hip_stream);
 int emme_ctx_dim(const emme_ctx_t* ctx); /* N if beta_e == 0 else 2N */
-/* Kernel family used by the last fill: 0 lanes-are-nodes, 1 omega-lane, 2 HBM node cache. */
+/* Kernel family used by the last fill: 0 lanes-are-nodes, 1 omega-lane, 2 HBM node cache
+ * (independent lanes), 3 HBM node cache + phase table, union walk. */
 int emme_ctx_fill_mode(const emme_ctx_t* ctx);
 /* GiB of HBM currently held by the node-record cache (0 if none). */
 double emme_ctx_node_cache_gib(const emme_ctx_t* ctx);
