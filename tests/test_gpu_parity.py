@@ -274,10 +274,18 @@ def test_trace_solve_sizes_against_lapack(emme, n):
 
 # ---- every fill kernel, forced through the context's environment switches ------------------
 KERNEL_MODES = {
-    # HBM node cache + independent-lane kernel (default), uncached integrals via work list
+    # HBM node cache, folded records + phase table; electrostatic GK15: union-walk kernel, EM / GK31:
+    # independent lanes (the defaults); uncached integrals via the work list
     "cached": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1"},
+    # the same with the independent-lane kernel for every case
+    "cached-independent": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
+    # unfolded records, exp(A0 + T omega) evaluated per (pair, node, omega) in the fill
+    "cached-unfolded": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_PHASE_TABLE": "0"},
+    # electromagnetic cases with one record per moment instead of the shared layout
+    "cached-em-per-moment": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_EM_SHARED": "0"},
     # cache too small for anything but the shallowest tree: most integrals are deferred
     "cached-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1"},
+    "cached-tiny-independent": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
     # no cache: omega-lane kernel (node data shared on the fly inside a lane group)
     "omega-lane": {"EMME_NODE_CACHE_GB": "0", "EMME_WL_MIN": "1"},
     # no cache, lanes-are-nodes kernel only
@@ -310,7 +318,7 @@ def test_every_fill_kernel_matches_oracle(emme, oracle, mode, monkeypatch):
             assert np.abs(M[k] - Mo).max() <= tol * np.abs(Mo).max(), (mode, d["conf"], w)
 
 
-@pytest.mark.parametrize("mode", ["cached", "omega-lane", "nodes"])
+@pytest.mark.parametrize("mode", ["cached", "cached-independent", "cached-unfolded", "omega-lane", "nodes"])
 def test_root_search_same_in_every_kernel_mode(emme, oracle, mode, monkeypatch):
     for k, v in KERNEL_MODES[mode].items():
         monkeypatch.setenv(k, v)
