@@ -87,6 +87,13 @@ struct emme_ctx {
     bool folded = true;        // records carry exp(A0); exp(T omega) comes from a per-launch phase table
     void* d_etab = nullptr;    // phase table of the current launch
     size_t etab_bytes = 0;
+    std::vector<int> h_lu_items;   // blocked LU: the live matrices of the launch (host / device)
+    int* d_lu_items = nullptr;
+    int lu_items_cap = 0;
+    void* d_lu_scratch = nullptr;  // blocked LU: diagonal of X, hand-over flags, row-map snapshots
+    size_t lu_scratch_bytes = 0;
+    int n_cu = 256;                // compute units of the device
+    int last_lu_nwg = 1;           // workgroups per matrix of the last LU launch
     bool ext_failed = false;
     unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
     double cache_bytes_used = 0.0;
@@ -284,11 +291,59 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
 }
 
 // the Newton linear step: blocked kernel while its panel fits in LDS, else the unblocked one
+// `n_live`: how many of the nbatch matrices are active (the others cost nothing); with fewer
+// live matrices than compute units each gets 2, 4 or 8 workgroups (EMME_LU_SPLIT=1 pins one).
 hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, const int* active,
-                       double* tr, int* info) {
+                       double* tr, int* info, const int* h_active) {
     static const bool force_unblocked = std::getenv("EMME_LU_UNBLOCKED") != nullptr;
-    if (!force_unblocked && trace_solve_blocked_lds(n) <= 150 * 1024)
-        return launch_trace_solve_blocked(n, nbatch, A, B, active, tr, info, c->stream);
+    const char* split_s = std::getenv("EMME_LU_SPLIT");  // read per call: the tests switch it
+    const int split_env = split_s ? std::atoi(split_s) : 0;
+    if (!force_unblocked && trace_solve_blocked_lds(n) <= 150 * 1024) {
+        const size_t need = trace_solve_blocked_scratch(n, nbatch);
+        if (need > c->lu_scratch_bytes) {
+            if (c->d_lu_scratch) (void)hipFree(c->d_lu_scratch);
+            c->d_lu_scratch = nullptr, c->lu_scratch_bytes = 0;
+            hipError_t e = hipMalloc(&c->d_lu_scratch, need);
+            if (e != hipSuccess) return e;
+            c->lu_scratch_bytes = need;
+        }
+        // dense list of the live matrices (h_active: host copy of `active`, null = all live)
+        int n_live = nbatch;
+        if (h_active) {
+            c->h_lu_items.clear();
+            for (int b = 0; b < nbatch; ++b)
+                if (h_active[b]) c->h_lu_items.push_back(b);
+            n_live = (int)c->h_lu_items.size();
+            if (n_live == 0) return hipSuccess;
+        }
+        int nwg = 1;
+        if (split_env > 0) {
+            nwg = std::min(split_env, 16);
+        } else if (n >= 128) {
+            // every workgroup of a matrix must be resident at once (they wait for each other):
+            // never more workgroups than compute units.  Below n = 128 the hand-over costs more
+            // than the idle units are worth, and beyond 4 the factoring workgroup is the limit.
+            while (nwg < 4 && n_live * nwg * 2 <= c->n_cu) nwg *= 2;
+        }
+        if (n_live * nwg > c->n_cu && split_env <= 0) nwg = 1;
+        c->last_lu_nwg = nwg;
+        const int* d_items = nullptr;
+        if (nwg > 1 && h_active) {
+            if (nbatch > c->lu_items_cap) {
+                if (c->d_lu_items) (void)hipFree(c->d_lu_items);
+                c->d_lu_items = nullptr, c->lu_items_cap = 0;
+                hipError_t e = hipMalloc((void**)&c->d_lu_items, sizeof(int) * nbatch);
+                if (e != hipSuccess) return e;
+                c->lu_items_cap = nbatch;
+            }
+            hipError_t e = hipMemcpyAsync(c->d_lu_items, c->h_lu_items.data(), sizeof(int) * n_live,
+                                          hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) return e;
+            d_items = c->d_lu_items;
+        }
+        return launch_trace_solve_blocked(n, nbatch, A, B, active, tr, info, nwg, d_items, n_live,
+                                          c->d_lu_scratch, c->stream);
+    }
     return launch_trace_solve(n, nbatch, A, B, active, tr, info, c->stream);
 }
 
@@ -296,7 +351,8 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
 //   trace-secant (include/solver.h:113-160): work <- M, LU of [work | Mp], tr(M^-1 M')
 //   QR-secant    (include/solver.h:210-383): work <- M^T, pivoted QR of work, t_n / R_nn
 hipError_t linear_step(emme_ctx* c, int method, int n, int nbatch, const double* M, double* work,
-                       double* Mp, const int* active, double* tr, int* info) {
+                       double* Mp, const int* active, double* tr, int* info,
+                       const int* h_active = nullptr) {
     const size_t mbytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
     if (method == EMME_METHOD_QR_SECANT) {
         hipError_t e = launch_transpose(n, nbatch, M, work, active, c->stream);
@@ -305,7 +361,7 @@ hipError_t linear_step(emme_ctx* c, int method, int n, int nbatch, const double*
     }
     hipError_t e = hipMemcpyAsync(work, M, mbytes, hipMemcpyDeviceToDevice, c->stream);
     if (e != hipSuccess) return e;
-    return trace_solve(c, n, nbatch, work, Mp, active, tr, info);
+    return trace_solve(c, n, nbatch, work, Mp, active, tr, info, h_active);
 }
 
 int check_method(const emme_ctx* c, int method) {
@@ -667,6 +723,7 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     emme_ctx* c = new emme_ctx;
     c->p = *p;
     c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
     if (const char* e = std::getenv("EMME_CACHE_MIN_BATCH")) c->cache_min_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("EMME_NODE_CACHE_GB")) c->cache_budget_gb = std::atof(e);
@@ -747,6 +804,8 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     }
     F(c->d_scale);
     F(c->d_etab);
+    F(c->d_lu_scratch);
+    F(c->d_lu_items);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -859,7 +918,7 @@ int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* 
     }
     {
         ScopedSpan s(c, K_LIN);
-        HIP_TRY(trace_solve(c, n, nbatch, dA, dB, nullptr, c->d_tr, c->d_info));
+        HIP_TRY(trace_solve(c, n, nbatch, dA, dB, nullptr, c->d_tr, c->d_info, nullptr));
     }
     HIP_TRY(hipMemcpyAsync(tr, c->d_tr, sizeof(double) * 2 * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
@@ -1061,7 +1120,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         }
         {
             ScopedSpan s(c, K_LIN);
-            HIP_TRY(linear_step(c, method, c->dim, n, c->d_M, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info));
+            HIP_TRY(linear_step(c, method, c->dim, n, c->d_M, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info, act.data()));
         }
         {
             ScopedSpan s(c, K_OTHER);
@@ -1093,6 +1152,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
                 iv_prev_dbg[b] = iv_now[b];
                 na += act[b] != 0;
             }
+            fprintf(stderr, "[emme] LU workgroups per matrix %d\n", c->last_lu_nwg);
             fprintf(stderr, "[emme] iter %2d: assembled %3d, lane-intervals %10llu (max/item %9llu), rounds %9llu, fill %.3f, still active %d\n",
                     j, nprev, tot, mx, r - last_rounds, tot / (16.0 * (double)(r - last_rounds + 1)), na);
             last_rounds = r;

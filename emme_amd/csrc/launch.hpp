@@ -90,9 +90,14 @@ hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int
                               double* tr /*2*nbatch*/, int* info, hipStream_t stream);
 
 // Blocked version (linstep_blocked.hip); usable while its LDS panel fits (n <= ~560).
+// nwg workgroups per matrix (1: one does everything; > 1: one factors A, the others carry B's
+// columns; `items` = device list of the nitems matrices to work on, null for all of them);
+// `scratch` holds trace_solve_blocked_scratch(n, nbatch) bytes.
 size_t trace_solve_blocked_lds(int n);
+size_t trace_solve_blocked_scratch(int n, int nbatch);
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
-                                      double* tr, int* info, hipStream_t stream);
+                                      double* tr, int* info, int nwg, const int* items, int nitems,
+                                      void* scratch, hipStream_t stream);
 
 // QR-secant form of the step (linstep_qr.hip, reference include/solver.h:210-383): Wt holds the
 // TRANSPOSE of each matrix (destroyed), Mp the secant derivative (read only); writes

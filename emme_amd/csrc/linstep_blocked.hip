@@ -18,6 +18,9 @@
 //            block in LDS (tiles right of the diagonal are skipped).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "emme_device.hpp"
 #include "launch.hpp"
 
@@ -74,8 +77,7 @@ struct BlkShared {
     double s_val[BW];
     int s_idx[BW];
     int info;
-    int nrem;
-    double tr[2];
+    int go;
 };
 
 // C(rows, cols) -= A(rows, 0:nbk) * B(0:nbk, cols) for complex matrices on the FP64 matrix cores:
@@ -160,16 +162,97 @@ __device__ __forceinline__ void mfma_update(int n, double2* a, double2* bb, cons
 }
 
 
-__global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, double2* B,
+// T1 of the trailing update: finish the NB pivot rows of columns Jlo .. Jhi-1 of [a | bb] (unit-
+// lower solve with L11, one column per lane in registers) and store them: they are rows of U
+// and of L^-1 P B.
+__device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb, const int* rowmap,
+                                                  const double2* L11, int k0, int nbk, int Jlo,
+                                                  int Jhi, int wave, int lane) {
+    const int nchunks = (Jhi - Jlo + 63) / 64;
+    for (int q = wave; q < nchunks; q += BW) {
+        const int J = Jlo + q * 64 + lane;
+        if (J < Jhi) {
+            double2* col = J < n ? a + J : bb + (J - n);
+            cd u[NB];
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk)
+                u[kk] = kk < nbk ? ldg(col + (size_t)rowmap[k0 + kk] * n) : mk(0.0, 0.0);
+#pragma unroll
+            for (int kk = 1; kk < NB; ++kk) {
+                if (kk < nbk) {
+#pragma unroll
+                    for (int c = 0; c < kk; ++c) {
+                        const double2 l = L11[kk * NB + c];
+                        u[kk] = u[kk] - mk(l.x, l.y) * u[c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk)
+                if (kk < nbk) stg(col + (size_t)rowmap[k0 + kk] * n, u[kk]);
+        }
+    }
+}
+
+// ---- several workgroups per matrix ---------------------------------------------------------
+// With fewer matrices than compute units a launch of one workgroup per matrix leaves CUs idle, so
+// a matrix can be given nwg = 1 + S workgroups ("roles"; role = blockIdx.x / nitems, so that every
+// role-0 workgroup is dispatched before any other):
+//   forward  role 0 factors A (panel + trailing A columns) and publishes, per panel, the
+//            multipliers (in A below the diagonal), the row order (a snapshot of the row map) and
+//            a counter; roles 1..S each own a range of B's columns and apply the published panels
+//            to it (producer -> consumer only: role 0 never waits in this phase).
+//   back     when U and L^-1 P B are complete every role takes a range of columns of the
+//            truncated back substitution, cut so that the ranges cost the same.
+//   trace    X(c,c) goes to a scratch vector and the last workgroup to arrive adds it up in a
+//            fixed order: the result does not depend on nwg, bit for bit.
+// Cross-workgroup hand-over: workgroup barrier, then ONE thread's agent-scope release store /
+// acquire load (they write back / invalidate this XCD's L2: the per-XCD L2s are not coherent
+// with each other otherwise), then a barrier again on the consumer side.
+// Waits are bounded: a time-out retires the matrix with info = EMME_EDEVICE instead of hanging.
+struct SplitCtl {
+    int nwg;
+    int nitems;        // matrices of this launch: role = blockIdx.x / nitems
+    const int* items;  // their indices in the batch (null: 0 .. nitems-1).  A dense list, so that
+                       // the workgroups spread evenly over the XCDs (block i runs on XCD i % 8)
+    int* flags;     // [nbatch][4]: panels published | B ranges finished | arrivals | unused
+    int* rowmaps;   // [nbatch][nblk][n]  (nwg > 1 only)
+    double2* diag;  // [nbatch][n]
+};
+constexpr int ABORT = 1 << 30;
+constexpr long SPIN_LIMIT = 3000000;
+constexpr int INFO_TIMEOUT = -3;  // EMME_EDEVICE
+
+__device__ __forceinline__ int spin_ge(int* p, int v) {
+    // relaxed polling (an acquire load would invalidate the XCD's L2 on every trip), one
+    // acquire fence once the value is there
+    for (long it = 0; it < SPIN_LIMIT; ++it) {
+        const int x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x >= v) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return x;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return -1;
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, double2* A, double2* B,
                                                             const int* active, double2* tr_out,
-                                                            int* info_out) {
+                                                            int* info_out, SplitCtl ctl) {
     // dynamic LDS: rowmap[n] | physrow[n] | pivof[n] (ints) | L11[NB][NB] | prow[NB] |
     //              panel[n][NB] (L21 in the forward phase, U column block in the back phase)
     extern __shared__ double2 lds2[];
     __shared__ BlkShared sh;
 
-    const int b = blockIdx.x;
+    const int role = SPLIT ? blockIdx.x / ctl.nitems : 0;
+    int b = blockIdx.x - role * ctl.nitems;
+    if (SPLIT && ctl.items) b = ctl.items[b];
     if (active && active[b] == 0) return;
+    const int nwg = SPLIT ? ctl.nwg : 1, S = nwg - 1;
+    int* flag_pub = ctl.flags + 4 * b;  // the hand-over state is touched for SPLIT only
+    int* snap = ctl.rowmaps + (size_t)b * ((n + NB - 1) / NB) * n;
     double2* a = A + (size_t)b * n * n;
     double2* bb = B + (size_t)b * n * n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,7 +265,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
     double2* panel = prow + NB;
 
     for (int r = tid; r < n; r += BT) rowmap[r] = r;
-    if (tid == 0) sh.info = 0, sh.tr[0] = 0.0, sh.tr[1] = 0.0;
+    if (tid == 0) sh.info = 0;
     __syncthreads();
 
     // column J of the augmented matrix: J < n -> A(:, J), else B(:, J - n)
@@ -190,7 +273,58 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         return J < n ? a + (size_t)prow_ * n + J : bb + (size_t)prow_ * n + (J - n);
     };
 
+    // whole-workgroup wait for *flag >= v; false on abort / time-out (the matrix is retired)
+    auto wg_wait = [&](int* flag, int v) -> bool {
+        if (tid == 0) sh.go = spin_ge(flag, v);
+        __syncthreads();
+        const int g = sh.go;
+        __syncthreads();
+        if (g < 0) {
+            if (tid == 0) {
+                tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
+                info_out[b] = INFO_TIMEOUT;
+                __hip_atomic_store(flag_pub, ABORT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return false;
+        }
+        // thread 0's acquire fence invalidated this CU's L1 / this XCD's L2 before the barrier
+        return g < ABORT;
+    };
+    // 16-aligned cuts of the column range [0, n)
+    auto cut16 = [&](double frac) -> int {
+        const int c = ((int)(frac * n) + 8) / 16 * 16;
+        return c < n ? c : n;
+    };
+
     // ================= forward elimination, NB columns per step =======================
+    if (SPLIT && role > 0) {
+        // ---- roles 1..S: apply the published panels to B's columns f0 .. f1-1 ---------------
+        const int f0 = cut16((double)(role - 1) / S);
+        const int f1 = role == S ? n : cut16((double)role / S);
+        for (int k0 = 0, kblk = 0; k0 < n; k0 += NB, ++kblk) {
+            const int nbk = min(NB, n - k0);
+            const int nrem = n - k0;
+            if (!wg_wait(flag_pub, kblk + 1)) return;
+            for (int r = tid; r < nrem; r += BT) rowmap[k0 + r] = snap[(size_t)kblk * n + k0 + r];
+            __syncthreads();
+            for (int e = tid; e < NB * NB; e += BT) {
+                const int kk = e / NB, c = e % NB;
+                L11[e] = (kk < nbk && c < kk) ? a[(size_t)rowmap[k0 + kk] * n + k0 + c]
+                                              : make_double2(0.0, 0.0);
+            }
+            for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+                const int r = e / NB, c = e % NB;
+                panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c]
+                                            : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, n + f0, n + f1, wave, lane);
+            __syncthreads();
+            if (f1 > f0)
+                mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, n + f0, f1 - f0, wave, lane);
+            __syncthreads();
+        }
+    } else
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nbk = min(NB, n - k0);
         const int nrem = n - k0;  // rows still in play; slot t <-> logical position k0 + t
@@ -286,15 +420,38 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         }
         __syncthreads();
 
+        if (SPLIT) {
+            // helpers read the multipliers from A (the usual in-place LU layout: L below / left
+            // of the pivots; copied here from LDS) and the row order from a snapshot
+            const int kblk = k0 / NB;
+            if (tid < nrem) snap[(size_t)kblk * n + k0 + tid] = rowmap[k0 + tid];
+            for (int e = tid; e < NB * NB; e += BT) {
+                const int kk = e / NB, c = e % NB;
+                if (kk < nbk && c < kk) a[(size_t)rowmap[k0 + kk] * n + k0 + c] = L11[e];
+            }
+            for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+                const int r = e / NB, c = e % NB;
+                if (c < nbk) a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] = panel[r * LS + c];
+            }
+            __syncthreads();  // every thread's stores are performed; thread 0 releases them
+            if (tid == 0)
+                __hip_atomic_store(flag_pub, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // ---- trailing update, one column per lane -------------------------------------------
-        const int J0 = k0 + nbk;           // first trailing column of A
-        const int ncols = 2 * n - J0;      // trailing A columns + all of B
+        // (thread coordinates recomputed from an opaque copy: whatever the update derives from
+        // them must not stay live across the panel loop, which needs the registers itself)
+        int tid_t = tid;
+        if (SPLIT) asm volatile("" : "+v"(tid_t));  // (the one-workgroup build is better off without)
+        const int lane = tid_t & 63, wave = SPLIT ? __builtin_amdgcn_readfirstlane(tid_t >> 6) : tid_t >> 6;
+        const int J0 = k0 + nbk;              // first trailing column of A
+        const int Jend = SPLIT ? n : 2 * n;   // trailing A columns (+ all of B without helpers)
+        const int ncols = Jend - J0;
         const int nchunks = (ncols + 63) / 64;
         // T1: finish the NB pivot rows of every column (unit-lower solve with L11 in
         //     registers) and store them: they are rows of U and of L^-1 P B.
         for (int q = wave; q < nchunks; q += BW) {
             const int J = J0 + q * 64 + lane;
-            if (J < 2 * n) {
+            if (J < Jend) {
                 cd u[NB];
 #pragma unroll
                 for (int kk = 0; kk < NB; ++kk)
@@ -316,27 +473,43 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         }
         __syncthreads();
         // T2: X(rows below the block, trailing columns) -= L21 * U12 on the matrix cores
-        mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, J0, ncols, wave, lane);
+        if (!SPLIT || ncols > 0)
+            mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, J0, ncols, wave, lane);
         __syncthreads();
     }
 
     __syncthreads();  // sh.info (written by thread 0 on a singular column) is visible
-    if (sh.info != 0) {
+    if (sh.info != 0) {  // role 0 only
         if (tid == 0) {
             tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
             info_out[b] = sh.info;
+            if (SPLIT) __hip_atomic_store(flag_pub, ABORT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
+    }
+    int c0 = 0, c1 = n;  // this role's columns of the back substitution
+    if (SPLIT) {
+        // L^-1 P B is complete when every helper has finished its columns
+        if (role > 0) {
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(flag_pub + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!wg_wait(flag_pub + 1, S)) return;
+        // column c costs (n - c)^2 / 2: equal shares of the sum
+        c0 = role == 0 ? 0 : cut16(1.0 - cbrt(1.0 - (double)role / nwg));
+        c1 = role == nwg - 1 ? n : cut16(1.0 - cbrt(1.0 - (double)(role + 1) / nwg));
     }
 
     // ================= truncated back substitution, NB rows per step ====================
     // rowmap is now the full pivot order: logical row r = physical row rowmap[r];
     // U(r, c) = a[rowmap[r]][c] for c >= r, and C = L^-1 P B sits in bb[rowmap[r]][:].
-    cd my_tr = mk(0.0, 0.0);
+    double2* diag = ctl.diag + (size_t)b * n;
     const int nblk = (n + NB - 1) / NB;
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * NB;
         const int nbk = min(NB, n - k0);
+        const int live = min(c1, k0 + nbk);  // columns c0 .. live-1 of C are still needed
+        if (live <= c0) break;               // uniform
         // U11 (upper NB x NB block, with reciprocal diagonal) and the U column block above it
         for (int e = tid; e < NB * NB; e += BT) {
             const int kk = e / NB, c = e % NB;
@@ -348,16 +521,16 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
             }
             L11[e] = v;
         }
-        for (int e = tid; e < k0 * NB; e += BT) {
+        for (int e = tid; e < (k0 - c0) * NB; e += BT) {  // rows c0 .. k0-1 (none if k0 <= c0)
             const int rr = e / NB, c = e % NB;
-            panel[rr * LS + c] = c < nbk ? *(&a[(size_t)rowmap[rr] * n + k0 + c]) : make_double2(0.0, 0.0);
+            panel[rr * LS + c] = c < nbk ? *(&a[(size_t)rowmap[c0 + rr] * n + k0 + c]) : make_double2(0.0, 0.0);
         }
         __syncthreads();
-        const int ncols = k0 + nbk;  // columns 0 .. k1-1 of C are still needed
+        const int ncols = live - c0;
         const int nchunks = (ncols + 63) / 64;
         for (int q = wave; q < nchunks; q += BW) {
-            const int c = q * 64 + lane;
-            const bool okc = c < ncols;
+            const int c = c0 + q * 64 + lane;
+            const bool okc = c < live;
             cd x[NB];
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk)
@@ -378,7 +551,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
                     const double2 rd = L11[kk * NB + kk];
                     s = s * mk(rd.x, rd.y);
                     x[kk] = (k0 + kk >= c) ? s : mk(0.0, 0.0);
-                    if (okc && k0 + kk == c) my_tr = my_tr + s;
+                    if (okc && k0 + kk == c) diag[c] = make_double2(s.x, s.y);
                 }
             }
             // the solved block replaces C's block rows: it is the B operand of the update below
@@ -391,28 +564,33 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, double2* A, d
         __syncthreads();
         // rows above the block: C(rr, c) -= sum_k U(rr, k0+k) X(k0+k, c), needed for rr >= c only
         // (column tiles right of the row tile are skipped)
-        mfma_update<true>(n, a, bb, rowmap, panel, 0, k0, k0, nbk, n, ncols, wave, lane);
+        if (k0 > c0)
+            mfma_update<true>(n, a, bb, rowmap, panel, c0, k0 - c0, k0, nbk, n + c0, ncols, wave, lane);
         __syncthreads();
     }
-    // trace = sum of the per-lane diagonal pieces
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        my_tr.x += __shfl_xor(my_tr.x, off);
-        my_tr.y += __shfl_xor(my_tr.y, off);
+    // trace = sum of X(c,c) in a fixed order, by the last workgroup of this matrix to get here
+    __syncthreads();
+    if (SPLIT) {
+        if (tid == 0)
+            sh.go = __hip_atomic_fetch_add(flag_pub + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sh.go != nwg - 1) return;
     }
-    if (lane == 0) sh.s_val[wave] = my_tr.x;
-    __syncthreads();
-    double trx = 0.0;
-    if (tid == 0)
-        for (int w = 0; w < BW; ++w) trx += sh.s_val[w];
-    __syncthreads();
-    if (lane == 0) sh.s_val[wave] = my_tr.y;
-    __syncthreads();
-    if (tid == 0) {
-        double try_ = 0.0;
-        for (int w = 0; w < BW; ++w) try_ += sh.s_val[w];
-        tr_out[b] = make_double2(trx, try_);
-        info_out[b] = 0;
+    if (wave == 0) {
+        cd t = mk(0.0, 0.0);
+        for (int c = lane; c < n; c += 64) {
+            const double2 v = diag[c];
+            t = t + mk(v.x, v.y);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            t.x += __shfl_xor(t.x, off);
+            t.y += __shfl_xor(t.y, off);
+        }
+        if (lane == 0) {
+            tr_out[b] = make_double2(t.x, t.y);
+            info_out[b] = 0;
+        }
     }
 }
 
@@ -422,17 +600,42 @@ size_t trace_solve_blocked_lds(int n) {
     return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)n * LS) * sizeof(double2);
 }
 
+size_t trace_solve_blocked_scratch(int n, int nbatch) {
+    const size_t nblk = (size_t)(n + NB - 1) / NB;
+    return (size_t)nbatch * (4 * sizeof(int) + nblk * n * sizeof(int) + (size_t)n * sizeof(double2)) + 256;
+}
+
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
-                                      double* tr, int* info, hipStream_t stream) {
+                                      double* tr, int* info, int nwg, const int* items, int nitems,
+                                      void* scratch, hipStream_t stream) {
     const size_t lds = trace_solve_blocked_lds(n);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked,
+        (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_trace_solve_blocked, dim3(nbatch), dim3(BT), lds, stream, n, (double2*)A,
-                       (double2*)B, active, (double2*)tr, info);
+    if (nwg < 1) nwg = 1;
+    // scratch: diag | flags | row-map snapshots
+    SplitCtl ctl;
+    ctl.nwg = nwg;
+    ctl.items = items;
+    ctl.nitems = items ? nitems : nbatch;
+    ctl.diag = (double2*)scratch;
+    ctl.flags = (int*)(ctl.diag + (size_t)nbatch * n);
+    ctl.rowmaps = ctl.flags + 4 * (size_t)nbatch;
+    if (nwg > 1) {
+        hipError_t e = hipMemsetAsync(ctl.flags, 0, 4 * sizeof(int) * (size_t)nbatch, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (nwg > 1)
+        hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream, n,
+                           nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+    else
+        hipLaunchKernelGGL(k_trace_solve_blocked<false>, dim3(nbatch), dim3(BT), lds, stream, n,
+                           nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
     return hipGetLastError();
 }
 

@@ -272,6 +272,32 @@ def test_trace_solve_sizes_against_lapack(emme, n):
         assert abs(tr[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, tr[b], want)
 
 
+@pytest.mark.parametrize("n,nwg", [(256, 2), (256, 4), (200, 3), (130, 2), (37, 2), (512, 4), (16, 8)])
+def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
+    """The LU with 1 + S workgroups per matrix (role 0 factors A, the others carry B's columns,
+    all share the back substitution): bit-identical to the one-workgroup launch, incl. ragged
+    sizes, an inactive-looking singular neighbour and sizes below one panel per helper."""
+    rng = np.random.default_rng(1000 * n + nwg)
+    nb = 5
+    A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    A = A + np.transpose(A, (0, 2, 1)) + 0.5 * n ** 0.5 * np.eye(n)
+    B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    A[3, :, n // 2] = 0.0  # matrix 3 is exactly singular at column n/2 + 1
+    with _ctx(emme, example_tokamak(npoints=16)) as ctx:
+        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        tr1, info1 = ctx.trace_solve(A, B)
+        monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
+        trs, infos = ctx.trace_solve(A, B)
+    assert info1[3] == n // 2 + 1 and np.array_equal(info1, infos)
+    assert np.isnan(trs[3].real) and np.isnan(tr1[3].real)
+    ok = np.arange(nb) != 3
+    assert (info1[ok] == 0).all()
+    assert np.array_equal(tr1[ok].view(np.float64), trs[ok].view(np.float64))  # bit for bit
+    for b in np.flatnonzero(ok):
+        want = np.trace(np.linalg.solve(A[b], B[b]))
+        assert abs(trs[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, trs[b], want)
+
+
 # ---- every fill kernel, forced through the context's environment switches ------------------
 KERNEL_MODES = {
     # HBM node cache, folded records + phase table; electrostatic GK15: union-walk kernel, EM / GK31:

@@ -31,4 +31,6 @@ if kind == "qr":
     want = -1.0 / Oracle.qr_secant(A[0], B[0])[0]
 else:
     want = np.trace(np.linalg.solve(A[0], B[0]))
+    allw = np.trace(np.linalg.solve(A, B), axis1=1, axis2=2)
+    print(f"   all {nb} matrices: max rel err {np.max(np.abs(tr - allw) / np.abs(allw)):.1e}, info max {info.max()} min {info.min()}, split {os.environ.get('EMME_LU_SPLIT', 'auto')}")
 print(f"{kind} n={n} batch={nb}: {min(ts)*1e3:.2f} ms (median {np.median(ts)*1e3:.2f}); check rel err {abs(tr[0]-want)/abs(want):.1e}")
