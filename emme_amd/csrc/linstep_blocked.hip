@@ -220,7 +220,7 @@ struct SplitCtl {
     double2* diag;  // [nbatch][n]
 };
 constexpr int ABORT = 1 << 30;
-constexpr long SPIN_LIMIT = 3000000;
+constexpr long SPIN_LIMIT = 16000000;  // about 4 s
 constexpr int INFO_TIMEOUT = -3;  // EMME_EDEVICE
 
 __device__ __forceinline__ int spin_ge(int* p, int v) {
@@ -630,12 +630,24 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         hipError_t e = hipMemsetAsync(ctl.flags, 0, 4 * sizeof(int) * (size_t)nbatch, stream);
         if (e != hipSuccess) return e;
     }
-    if (nwg > 1)
-        hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream, n,
-                           nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
-    else
-        hipLaunchKernelGGL(k_trace_solve_blocked<false>, dim3(nbatch), dim3(BT), lds, stream, n,
-                           nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+    if (nwg > 1) {
+        // The roles of a matrix wait for each other, so the whole grid has to be resident at
+        // once: a cooperative launch makes the runtime check exactly that (it refuses a grid the
+        // device cannot hold); then, or if cooperative launches are not available, one
+        // workgroup per matrix does the job.
+        double2* A2 = (double2*)A;
+        double2* B2 = (double2*)B;
+        double2* tr2 = (double2*)tr;
+        void* args[] = {&n, &nbatch, &A2, &B2, &active, &tr2, &info, &ctl};
+        const hipError_t e = hipLaunchCooperativeKernel((const void*)k_trace_solve_blocked<true>,
+                                                        dim3(ctl.nitems * nwg), dim3(BT), args,
+                                                        (unsigned)lds, stream);
+        if (e == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        ctl.nwg = 1;
+    }
+    hipLaunchKernelGGL(k_trace_solve_blocked<false>, dim3(nbatch), dim3(BT), lds, stream, n, nbatch,
+                       (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
     return hipGetLastError();
 }
 
