@@ -291,8 +291,8 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
 }
 
 // the Newton linear step: blocked kernel while its panel fits in LDS, else the unblocked one
-// `n_live`: how many of the nbatch matrices are active (the others cost nothing); with fewer
-// live matrices than compute units each gets 2, 4 or 8 workgroups (EMME_LU_SPLIT=1 pins one).
+// `h_active`: host copy of `active` (null: all live).  With fewer live matrices than compute
+// units each gets up to 4 workgroups (EMME_LU_SPLIT=k pins k; 1 = one workgroup per matrix).
 hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, const int* active,
                        double* tr, int* info, const int* h_active) {
     static const bool force_unblocked = std::getenv("EMME_LU_UNBLOCKED") != nullptr;
@@ -323,9 +323,8 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
             // every workgroup of a matrix must be resident at once (they wait for each other):
             // never more workgroups than compute units.  Below n = 128 the hand-over costs more
             // than the idle units are worth, and beyond 4 the factoring workgroup is the limit.
-            while (nwg < 4 && n_live * nwg * 2 <= c->n_cu) nwg *= 2;
+            nwg = std::max(1, std::min(4, c->n_cu / n_live));
         }
-        if (n_live * nwg > c->n_cu && split_env <= 0) nwg = 1;
         c->last_lu_nwg = nwg;
         const int* d_items = nullptr;
         if (nwg > 1 && h_active) {

@@ -632,18 +632,21 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
     }
     if (nwg > 1) {
         // The roles of a matrix wait for each other, so the whole grid has to be resident at
-        // once: a cooperative launch makes the runtime check exactly that (it refuses a grid the
-        // device cannot hold); then, or if cooperative launches are not available, one
-        // workgroup per matrix does the job.
-        double2* A2 = (double2*)A;
-        double2* B2 = (double2*)B;
-        double2* tr2 = (double2*)tr;
-        void* args[] = {&n, &nbatch, &A2, &B2, &active, &tr2, &info, &ctl};
-        const hipError_t e = hipLaunchCooperativeKernel((const void*)k_trace_solve_blocked<true>,
-                                                        dim3(ctl.nitems * nwg), dim3(BT), args,
-                                                        (unsigned)lds, stream);
-        if (e == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
+        // once: workgroups the device can hold (occupancy x compute units) >= grid, else one
+        // workgroup per matrix does the job.  (A cooperative launch would make the same check;
+        // it is not used because its extra queue crashes rocprofv3 at process exit.)
+        int per_cu = 0, dev = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        }
+        if ((long)per_cu * ncu >= (long)ctl.nitems * nwg) {
+            hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
+                               n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+            return hipGetLastError();
+        }
         ctl.nwg = 1;
     }
     hipLaunchKernelGGL(k_trace_solve_blocked<false>, dim3(nbatch), dim3(BT), lds, stream, n, nbatch,

@@ -298,6 +298,25 @@ def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
         assert abs(trs[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, trs[b], want)
 
 
+@pytest.mark.parametrize("nwg", [2, 3])
+def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
+    """Whole Newton searches with 1 and with several LU workgroups per matrix: same iterates,
+    same roots, bit for bit (chains retire at different steps, so the launches see dense lists
+    of live matrices of changing length)."""
+    d = example_tokamak(npoints=64)
+    guesses = np.array([-0.8 + 0.25j, -0.7 + 0.3j, -0.9 + 0.2j, -0.6 + 0.1j, -1.0 + 0.35j])
+    with _ctx(emme, d) as ctx:
+        ctx.solve_roots(guesses)  # builds the node cache: later fills are identical
+        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        r1, it1, info1, its1 = ctx.solve_roots(guesses, want_iterates=True)
+        monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
+        r2, it2, info2, its2 = ctx.solve_roots(guesses, want_iterates=True)
+    assert np.array_equal(it1, it2) and np.array_equal(info1, info2)
+    assert np.array_equal(its1.view(np.float64), its2.view(np.float64), equal_nan=True)
+    assert np.array_equal(r1.view(np.float64), r2.view(np.float64), equal_nan=True)
+    assert len(set(it1.tolist())) > 1  # the chains did retire at different steps
+
+
 # ---- every fill kernel, forced through the context's environment switches ------------------
 KERNEL_MODES = {
     # HBM node cache, folded records + phase table; electrostatic GK15: union-walk kernel, EM / GK31:
