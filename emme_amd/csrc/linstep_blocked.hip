@@ -635,14 +635,22 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         // once: workgroups the device can hold (occupancy x compute units) >= grid, else one
         // workgroup per matrix does the job.  (A cooperative launch would make the same check;
         // it is not used because its extra queue crashes rocprofv3 at process exit.)
-        int per_cu = 0, dev = 0, ncu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            per_cu = 0;
+        static size_t cap_lds = ~(size_t)0;  // capacity of the current device for this LDS size
+        static int cap_dev = -1;
+        static long cap = 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        if (dev < 0 || dev != cap_dev || lds != cap_lds) {
+            int per_cu = 0, ncu = 0;
+            if (dev < 0 ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds) != hipSuccess ||
+                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+                (void)hipGetLastError();
+                per_cu = 0;
+            }
+            cap = (long)per_cu * ncu, cap_dev = dev, cap_lds = lds;
         }
-        if ((long)per_cu * ncu >= (long)ctl.nitems * nwg) {
+        if (cap >= (long)ctl.nitems * nwg) {
             hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
                                n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
             return hipGetLastError();

@@ -298,6 +298,22 @@ def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
         assert abs(trs[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, trs[b], want)
 
 
+def test_trace_solve_split_falls_back_when_the_grid_cannot_be_resident(emme, monkeypatch):
+    """More workgroups than the device holds at once would wait for each other forever: the
+    launcher must notice and use one workgroup per matrix (same bits, no time-out codes)."""
+    rng = np.random.default_rng(5)
+    n, nb = 32, 100  # 100 matrices x 4 workgroups > 256 compute units x 1
+    A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n)) + 3.0 * np.eye(n)
+    B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    with _ctx(emme, example_tokamak(npoints=16)) as ctx:
+        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        tr1, info1 = ctx.trace_solve(A, B)
+        monkeypatch.setenv("EMME_LU_SPLIT", "4")
+        tr4, info4 = ctx.trace_solve(A, B)
+    assert (info1 == 0).all() and (info4 == 0).all()
+    assert np.array_equal(tr1.view(np.float64), tr4.view(np.float64))
+
+
 @pytest.mark.parametrize("nwg", [2, 3])
 def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
     """Whole Newton searches with 1 and with several LU workgroups per matrix: same iterates,
