@@ -130,11 +130,11 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this build
     (profiles/, separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md); bench.py cannot
     collect hardware counters itself.  Raw counter figures (no gfx950 x2 read correction)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v8_pmc_summary.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v9_pmc_summary.json")
     try:
         k = json.load(open(path))["kernels"][kernel]
         return (k["hbm_fetch_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
-                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v8_pmc_summary.json "
+                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v9_pmc_summary.json "
                 "(rocprofv3 --pmc passes over tools/iter_profile.py, same workload)")
     except (OSError, KeyError, ValueError):
         return None, "no PMC summary for this kernel under profiles/"
@@ -231,7 +231,7 @@ def main():
         # the cached kernel; they stream from HBM / Infinity Cache / L2) + dim^2 entries written
         # (16 B M, 16 B M', 16 B read of M_old in the fused secant epilogue)
         bytes_alg = prof.gk_intervals * 15 * 64.0 + prof.matrices * dim * dim * 48.0
-        traffic, traffic_note = pmc_traffic("k_assemble_union<15>")
+        traffic, traffic_note = pmc_traffic("k_assemble_union<15, 2>")
         out = {
             "metric": "omega-points solved/sec (256-pt grid)",
             "value": total_points / dt,

@@ -704,9 +704,10 @@ __device__ __forceinline__ unsigned long long row16_min_u64(unsigned long long v
     return v;
 }
 
-template <int PTS>
+template <int PTS, int NSEL>
 __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
     static_assert(PTS == 15, "lane groups of 16: GK15");
+    static_assert(NSEL >= 1 && NSEL <= 4, "intervals served per round");
     constexpr int GW = 16;
     constexpr int H = (PTS + 1) / 2;
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
     const double* gtab = lds_raw + N;
     const int group_in_block = threadIdx.x / GW;
     const int lane = threadIdx.x % GW;
-    double2* slots = reinterpret_cast<double2*>(lds_raw + 3 * N + ((3 * N) & 1)) + group_in_block * (GW * 3);
+    double2* slots = reinterpret_cast<double2*>(lds_raw + 3 * N + ((3 * N) & 1)) + group_in_block * (NSEL * GW * 3);
 
     const int2 chunk = A.chunks[blockIdx.y];
     const bool has_w = lane < chunk.y;
@@ -768,38 +769,53 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
         int count = 0;
         bool deferred = false;
         for (;;) {
-            // next interval of the union; a group whose omegas sit on both sides of the imaginary
-            // axis walks contour class 0 first (bit 63 of the group key), the records differ
+            // The NSEL smallest distinct keys of the group are served in one round (a group whose
+            // omegas sit on both sides of the imaginary axis walks contour class 0 first: bit 63
+            // of the group key, the records differ).  With NSEL = 1 this is the plain union walk;
+            // NSEL > 1 lets lanes whose trees have diverged advance in the same round -- each
+            // lane still needs nothing but its own next key.
             const unsigned long long mykey = key == DONE ? DONE : (key | ((unsigned long long)cls << 63));
-            const unsigned long long curk = row16_min_u64(mykey);
-            if (curk == DONE) break;  // group-uniform
-            const int ccls = (int)(curk >> 63);
-            const unsigned long long cur = curk & ~(1ull << 63);
-            const int depth = (int)(cur & 63ull);
-            const unsigned long long path = (cur >> 6) >> (KD - depth);
-            const bool mine = key == cur && cls == ccls;
-            int which;
-            const int cslot = A.geom.slot(depth, path, which);
-            const NodeRec* ebuf = which >= 0 ? A.recs_ext[ccls][which] : A.recs[ccls];
-            if (cslot < 0 || ebuf == nullptr) {
-                if (mine) {  // outside the cache: this omega's integral goes to the cooperative kernel
-                    const unsigned int slot = atomicAdd(A.worklist_count, 1u);
-                    A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
-                    A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)cls << 55) |
-                                         (path & 0x7fffffffffffffull);
-                    deferred = true;
-                    key = DONE;
+            unsigned long long ksel[NSEL];
+            ksel[0] = row16_min_u64(mykey);
+            if (ksel[0] == DONE) break;  // group-uniform
+#pragma unroll
+            for (int q = 1; q < NSEL; ++q)
+                ksel[q] = ksel[q - 1] == DONE ? DONE : row16_min_u64(mykey > ksel[q - 1] ? mykey : DONE);
+            int sel = -1;  // which of the served intervals is this lane's
+#pragma unroll
+            for (int q = 0; q < NSEL; ++q)
+                if (mykey == ksel[q] && mykey != DONE) sel = q;
+            int my_cslot = -1;
+            // ---- phase 1: lane = node, one coalesced 768-byte read per served interval ----------
+#pragma unroll
+            for (int q = 0; q < NSEL; ++q) {
+                if (ksel[q] == DONE) continue;  // group-uniform
+                const int ccls = (int)(ksel[q] >> 63);
+                const unsigned long long cur = ksel[q] & ~(1ull << 63);
+                const int depth = (int)(cur & 63ull);
+                const unsigned long long path = (cur >> 6) >> (KD - depth);
+                int which;
+                const int cslot = A.geom.slot(depth, path, which);
+                const NodeRec* ebuf = which >= 0 ? A.recs_ext[ccls][which] : A.recs[ccls];
+                if (cslot < 0 || ebuf == nullptr) {
+                    if (sel == q) {  // outside the cache: this omega's integral goes to the cooperative kernel
+                        const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+                        A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)item;
+                        A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)cls << 55) |
+                                             (path & 0x7fffffffffffffull);
+                        deferred = true;
+                        key = DONE;
+                        sel = -1;
+                    }
+                    continue;
                 }
-                continue;
-            }
-            // ---- phase 1: lane = node, one coalesced 768-byte read ------------------------------
-            {
                 const NodeRec* rp =
                     which < 0 ? ebuf + ((long)item * A.geom.ni_main() + cslot) * GW
                               : ebuf + ((long)item * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW;
                 const NodeRec rec = rp[lane];
-                double2* s = slots + lane * 3;
+                double2* s = slots + (q * GW + lane) * 3;
                 s[0] = rec.A0, s[1] = rec.Q1, s[2] = rec.Q0;
+                if (sel == q) my_cslot = cslot;
             }
             // the slots are produced and consumed inside one wave: LDS operations of a wave
             // complete in issue order; the fences keep the compiler from moving them
@@ -807,7 +823,11 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- phase 2: lane = omega -----------------------------------------------------------
-            if (mine) {
+            if (sel >= 0) {
+                const int cslot = my_cslot;
+                const int depth = (int)(key & 63ull);
+                const unsigned long long path = (key >> 6) >> (KD - depth);
+                const double2* myslots = slots + sel * (GW * 3);
                 const double2* tp = A.etab + (long)cslot * GW * A.n_act + wpos;
                 auto node_of = [&](int s) { return s == 0 ? 0 : ((s & 1) ? (s + 1) >> 1 : (s >> 1) + H - 1); };
                 double2 ev[PTS];
@@ -816,7 +836,7 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
                 cd K = mk(0.0, 0.0), G = mk(0.0, 0.0), fplus = mk(0.0, 0.0);
 #pragma unroll
                 for (int s = 0; s < PTS; ++s) {
-                    const double2* r = slots + node_of(s) * 3;
+                    const double2* r = myslots + node_of(s) * 3;
                     const double2 a0 = r[0], q1 = r[1], q0 = r[2];
                     const double2 tt = ev[s];
                     // safe_exp clamp (src/Parameters.cpp:167-173) as |exp(A0 + T omega)|^2 < exp(-80)
@@ -975,8 +995,17 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
         if (ugx < 1) ugx = 1;
         if (ugx > 65535) ugx = 65535;
         const size_t n0 = (size_t)3 * L.P.N;
-        const size_t ulds = (n0 + (n0 & 1)) * sizeof(double) + (size_t)16 * 16 * 3 * sizeof(double2);
-        hipLaunchKernelGGL((k_assemble_union<15>), dim3((unsigned)ugx, (unsigned)nchunks), block, ulds, stream, A);
+        // intervals served per round (EMME_UNION_SEL, default 2): see the kernel
+        const char* sel_s = std::getenv("EMME_UNION_SEL");
+        const int nsel = sel_s ? std::atoi(sel_s) : 2;
+        const size_t ulds0 = (n0 + (n0 & 1)) * sizeof(double);
+        const size_t slot_bytes = (size_t)16 * 16 * 3 * sizeof(double2);
+        if (nsel <= 1)
+            hipLaunchKernelGGL((k_assemble_union<15, 1>), dim3((unsigned)ugx, (unsigned)nchunks), block, ulds0 + slot_bytes, stream, A);
+        else if (nsel == 2)
+            hipLaunchKernelGGL((k_assemble_union<15, 2>), dim3((unsigned)ugx, (unsigned)nchunks), block, ulds0 + 2 * slot_bytes, stream, A);
+        else
+            hipLaunchKernelGGL((k_assemble_union<15, 4>), dim3((unsigned)ugx, (unsigned)nchunks), block, ulds0 + 4 * slot_bytes, stream, A);
     } else if (L.gk_points == 15 && etab)
         hipLaunchKernelGGL((k_assemble_cached<15, true>), grid, block, lds, stream, A);
     else if (L.gk_points == 15)
