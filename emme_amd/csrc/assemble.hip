@@ -49,6 +49,7 @@ struct AsmArgs {
     // moment m multiplies them by (c_nv W)^m with W from wtab (null = one record per moment)
     const double2* wtab[2];
     int folded;  // cached records are in the folded form (exp(A0) inside the amplitudes)
+    unsigned int count_lo, count_hi;  // k_assemble_coop: run only if count_lo <= list length < count_hi
 };
 
 // Value of the integrand at one quadrature node when a node-record cache may hold the
@@ -323,12 +324,13 @@ struct CoopEnt {
     int depth, pad;
 };
 
-template <int PTS>
-__global__ __launch_bounds__(256) void k_assemble_coop(AsmArgs A) {
+template <int PTS, int BT>
+__global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
-    constexpr int NG = 256 / GW;
-    constexpr int CAP = 1024;  // >= NG * (MAXD + 1)
+    constexpr int NG = BT / GW;
+    constexpr int CAP = 4 * BT;  // >= NG * (MAXD + 1)
     constexpr int MAXD = 40;
+    static_assert(CAP >= NG * (MAXD + 1), "stack bound of the deepest-first walk");
     extern __shared__ double lds_tab[];  // eta | g | b (3N doubles) | CoopEnt stack[CAP]
     __shared__ int s_cnt[NG];
     __shared__ double s_part[NG][2];
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(256) void k_assemble_coop(AsmArgs A) {
     const double qa = 0.0, qb = M_PI / 2.0;
     const double inv_scale = 2. / (qb - qa);
     const int nitems = (int)*A.worklist_count;
+    if ((unsigned)nitems < A.count_lo || (unsigned)nitems >= A.count_hi) return;  // the other variant's list
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const unsigned long long e = A.worklist[item];
@@ -577,12 +580,26 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     dim3 grid(2048), block(256);
     static const bool one_group = std::getenv("EMME_DEFER_ONE_GROUP") != nullptr;
     if (!one_group) {
-        // a workgroup per integral (see k_assemble_coop)
-        const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) + 1024 * sizeof(CoopEnt);
+        // a workgroup per integral (see k_assemble_coop): 256 threads for a short list (few, long
+        // integrals: as many lane groups per integral as its frontier can feed), one wave for a
+        // long one (thousands of integrals, mostly deep and narrow: more of them in flight and
+        // wave-level barriers).  The list length is on the device: both variants are launched
+        // and the one whose range it is not in returns at once.
+        const char* wide_s = std::getenv("EMME_COOP_WIDE_MIN");
+        const unsigned int wide_min = wide_s ? (unsigned int)std::atol(wide_s) : 4096u;
+        const size_t tab_bytes = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double);
+        A.count_lo = 0, A.count_hi = wide_min;
         if (L.gk_points == 15)
-            hipLaunchKernelGGL((k_assemble_coop<15>), grid, block, lds, stream, A);
+            hipLaunchKernelGGL((k_assemble_coop<15, 256>), grid, block, tab_bytes + 4 * 256 * sizeof(CoopEnt), stream, A);
         else
-            hipLaunchKernelGGL((k_assemble_coop<31>), grid, block, lds, stream, A);
+            hipLaunchKernelGGL((k_assemble_coop<31, 256>), grid, block, tab_bytes + 4 * 256 * sizeof(CoopEnt), stream, A);
+        if (wide_min != 0xffffffffu) {
+            A.count_lo = wide_min, A.count_hi = 0xffffffffu;
+            if (L.gk_points == 15)
+                hipLaunchKernelGGL((k_assemble_coop<15, 64>), dim3(4096), dim3(64), tab_bytes + 4 * 64 * sizeof(CoopEnt), stream, A);
+            else
+                hipLaunchKernelGGL((k_assemble_coop<31, 64>), dim3(4096), dim3(64), tab_bytes + 4 * 64 * sizeof(CoopEnt), stream, A);
+        }
         return hipGetLastError();
     }
     const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
