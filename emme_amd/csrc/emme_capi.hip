@@ -351,15 +351,17 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
 //   QR-secant    (include/solver.h:210-383): work <- M^T, pivoted QR of work, t_n / R_nn
 hipError_t linear_step(emme_ctx* c, int method, int n, int nbatch, const double* M, double* work,
                        double* Mp, const int* active, double* tr, int* info,
-                       const int* h_active = nullptr) {
+                       const int* h_active = nullptr, bool work_ready = false) {
     const size_t mbytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
     if (method == EMME_METHOD_QR_SECANT) {
         hipError_t e = launch_transpose(n, nbatch, M, work, active, c->stream);
         if (e != hipSuccess) return e;
         return launch_qr_secant(n, nbatch, work, Mp, active, tr, info, c->stream);
     }
-    hipError_t e = hipMemcpyAsync(work, M, mbytes, hipMemcpyDeviceToDevice, c->stream);
-    if (e != hipSuccess) return e;
+    if (!work_ready) {  // (the root search copies M -> work together with M -> Mold)
+        hipError_t e = hipMemcpyAsync(work, M, mbytes, hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) return e;
+    }
     return trace_solve(c, n, nbatch, work, Mp, active, tr, info, h_active);
 }
 
@@ -1071,7 +1073,6 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         HIP_TRY(hipMemcpyAsync(c->d_iterates, nanv.data(), need * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    const size_t mbytes = mat_doubles(c) * sizeof(double) * n;
 
     // EigenSolver ctor (include/solver.h:396-415): eigen_value = 0.99 g, d = 0.01 g;
     // M_old = M(eigen_value); eigen_value += d; M = M(eigen_value); M' = (M - M_old)/d
@@ -1113,13 +1114,18 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     rc = refresh_cost();
     if (rc) return rc;
     for (int j = 0; j <= step_limit; ++j) {  // src/main.cpp:43
+        const bool fused_copy = method == EMME_METHOD_TRACE_SECANT;
         {
+            // previous matrix for the secant (and the LU's work copy in the same pass), for the
+            // chains still iterating only
             ScopedSpan s(c, K_OTHER);
-            HIP_TRY(hipMemcpyAsync(c->d_Mold, c->d_M, mbytes, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(launch_copy_active(c->dim, n, c->d_M, c->d_Mold, fused_copy ? c->d_work : nullptr,
+                                       c->d_active, c->stream));
         }
         {
             ScopedSpan s(c, K_LIN);
-            HIP_TRY(linear_step(c, method, c->dim, n, c->d_M, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info, act.data()));
+            HIP_TRY(linear_step(c, method, c->dim, n, c->d_M, c->d_work, c->d_Mp, c->d_active, c->d_tr, c->d_info,
+                                act.data(), fused_copy));
         }
         {
             ScopedSpan s(c, K_OTHER);

@@ -89,6 +89,10 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
                               double* tr /*2*nbatch*/, int* info, hipStream_t stream);
 
+// dst1[b] = src[b] (and dst2[b], if given) for the active n x n matrices of the batch
+hipError_t launch_copy_active(int n, int nbatch, const double* src, double* dst1, double* dst2,
+                              const int* active, hipStream_t stream);
+
 // Blocked version (linstep_blocked.hip); usable while its LDS panel fits (n <= ~560).
 // nwg workgroups per matrix (1: one does everything; > 1: one factors A, the others carry B's
 // columns; `items` = device list of the nitems matrices to work on, null for all of them);

@@ -12,6 +12,8 @@
 // them at LDS rate and streams its own rows with coalesced 16-byte accesses.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "emme_device.hpp"
 #include "launch.hpp"
 
@@ -202,6 +204,22 @@ __global__ void k_secant(size_t nn, const double2* M, const double2* Mold, const
     }
 }
 
+// dst1[b] = src[b] (and dst2[b] = src[b] if dst2) for the active matrices of the batch only: the
+// Newton loop's "previous matrix" and LU work copies, which shrink with the live chains
+__global__ __launch_bounds__(256) void k_copy_active(long elems, const double2* src, double2* dst1,
+                                                     double2* dst2, const int* active) {
+    const int b = blockIdx.y;
+    if (active && active[b] == 0) return;
+    const double2* s = src + (size_t)b * elems;
+    double2* d1 = dst1 + (size_t)b * elems;
+    double2* d2 = dst2 ? dst2 + (size_t)b * elems : nullptr;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < elems; e += (long)gridDim.x * blockDim.x) {
+        const double2 v = s[e];
+        d1[e] = v;
+        if (d2) d2[e] = v;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
@@ -234,6 +252,15 @@ hipError_t launch_secant(int nbatch, size_t nn, const double* M, const double* M
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k_secant, dim3(gx, nbatch), dim3(256), 0, stream, nn, (const double2*)M,
                        (const double2*)Mold, (const double2*)domega, active, (double2*)Mp);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_active(int n, int nbatch, const double* src, double* dst1, double* dst2,
+                              const int* active, hipStream_t stream) {
+    const long elems = (long)n * n;
+    const unsigned gx = (unsigned)std::min<long>(64, (elems + 255) / 256);
+    hipLaunchKernelGGL(k_copy_active, dim3(gx, nbatch), dim3(256), 0, stream, elems, (const double2*)src,
+                       (double2*)dst1, (double2*)dst2, active);
     return hipGetLastError();
 }
 
