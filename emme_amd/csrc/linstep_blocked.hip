@@ -251,6 +251,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     if (SPLIT && ctl.items) b = ctl.items[b];
     if (active && active[b] == 0) return;
     const int nwg = SPLIT ? ctl.nwg : 1, S = nwg - 1;
+    // look-ahead (4 or more workgroups): role 0 applies a panel only to the NEXT panel's columns,
+    // role 1 to the rest of A, so that A's trailing update leaves the factoring critical path
+    const bool la = SPLIT && ctl.nwg >= 4;
     int* flag_pub = ctl.flags + 4 * b;  // the hand-over state is touched for SPLIT only
     int* snap = ctl.rowmaps + (size_t)b * ((n + NB - 1) / NB) * n;
     double2* a = A + (size_t)b * n * n;
@@ -299,8 +302,12 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     // ================= forward elimination, NB columns per step =======================
     if (SPLIT && role > 0) {
         // ---- roles 1..S: apply the published panels to B's columns f0 .. f1-1 ---------------
-        const int f0 = cut16((double)(role - 1) / S);
-        const int f1 = role == S ? n : cut16((double)role / S);
+        // (with look-ahead, role 1 instead carries A's trailing columns beyond the next panel
+        // and reports every finished step in flags[3]; roles 2..S share B)
+        const bool a_helper = la && role == 1;
+        const int hB = la ? S - 1 : S, rB = la ? role - 2 : role - 1;  // B helpers / this one's rank
+        const int f0 = a_helper ? 0 : cut16((double)rB / hB);
+        const int f1 = a_helper ? 0 : (rB == hB - 1 ? n : cut16((double)(rB + 1) / hB));
         for (int k0 = 0, kblk = 0; k0 < n; k0 += NB, ++kblk) {
             const int nbk = min(NB, n - k0);
             const int nrem = n - k0;
@@ -318,11 +325,16 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                                             : make_double2(0.0, 0.0);
             }
             __syncthreads();
-            pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, n + f0, n + f1, wave, lane);
+            // this role's columns of [A | B] at this step
+            const int Jlo = a_helper ? min(n, k0 + nbk + NB) : n + f0;
+            const int Jhi = a_helper ? n : n + f1;
+            pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, Jlo, Jhi, wave, lane);
             __syncthreads();
-            if (f1 > f0)
-                mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, n + f0, f1 - f0, wave, lane);
-            __syncthreads();
+            if (Jhi > Jlo)
+                mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, Jlo, Jhi - Jlo, wave, lane);
+            __syncthreads();  // (every thread's stores are performed; thread 0 releases them)
+            if (a_helper && tid == 0)
+                __hip_atomic_store(flag_pub + 3, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else
     for (int k0 = 0; k0 < n; k0 += NB) {
@@ -444,7 +456,12 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         if (SPLIT) asm volatile("" : "+v"(tid_t));  // (the one-workgroup build is better off without)
         const int lane = tid_t & 63, wave = SPLIT ? __builtin_amdgcn_readfirstlane(tid_t >> 6) : tid_t >> 6;
         const int J0 = k0 + nbk;              // first trailing column of A
-        const int Jend = SPLIT ? n : 2 * n;   // trailing A columns (+ all of B without helpers)
+        if (SPLIT && la && k0 > 0 && J0 < n) {
+            // panel j goes onto block j+1 after role 1 has put panels 0 .. j-1 there
+            if (!wg_wait(flag_pub + 3, k0 / NB)) return;
+        }
+        // trailing A columns (+ all of B without helpers; the next panel's only with look-ahead)
+        const int Jend = SPLIT ? (la ? min(n, J0 + NB) : n) : 2 * n;
         const int ncols = Jend - J0;
         const int nchunks = (ncols + 63) / 64;
         // T1: finish the NB pivot rows of every column (unit-lower solve with L11 in
