@@ -292,7 +292,7 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
 
 // the Newton linear step: blocked kernel while its panel fits in LDS, else the unblocked one
 // `h_active`: host copy of `active` (null: all live).  With fewer live matrices than compute
-// units each gets up to 4 workgroups (EMME_LU_SPLIT=k pins k; 1 = one workgroup per matrix).
+// units each gets up to 8 workgroups (EMME_LU_SPLIT=k pins k; 1 = one workgroup per matrix).
 hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, const int* active,
                        double* tr, int* info, const int* h_active) {
     static const bool force_unblocked = std::getenv("EMME_LU_UNBLOCKED") != nullptr;
@@ -322,8 +322,9 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
         } else if (n >= 128) {
             // every workgroup of a matrix must be resident at once (they wait for each other):
             // never more workgroups than compute units.  Below n = 128 the hand-over costs more
-            // than the idle units are worth, and beyond 4 the factoring workgroup is the limit.
-            nwg = std::max(1, std::min(4, c->n_cu / n_live));
+            // than the idle units are worth, and beyond 8 the factoring workgroup is the limit.
+            // (n = 256: four are enough, role 0 is the limit then; n = 512: two A-helpers pay)
+            nwg = std::max(1, std::min(n >= 384 ? 8 : 4, c->n_cu / n_live));
         }
         c->last_lu_nwg = nwg;
         const int* d_items = nullptr;

@@ -1,11 +1,12 @@
 // linstep_blocked.hip -- blocked form of the Newton linear step tr(M^-1 M') (see linstep.hip
 // for the unblocked reference version and the algorithmic notes).
 //
-// One workgroup (1024 threads) per batch item, block size NB = 16:
+// One workgroup (1024 threads) per batch item -- or several, see "several workgroups per matrix"
+// below -- block size NB = 16:
 //   panel    the NB current columns of every remaining row live in REGISTERS of the row's
 //            owner thread; partial pivoting = block argmax per column, the winner publishes
 //            its row through LDS; no row is ever moved in memory (a row map keeps the pivot
-//            order).  Multipliers never go to global memory.
+//            order).  Multipliers go to global memory only for helper workgroups.
 //   trailing T1: each lane owns one column J of the augmented matrix [A | B], loads the NB
 //            pivot-row entries of that column, finishes them with the NB x NB unit-lower block
 //            (forward substitution in registers) and stores them: rows of U / of L^-1 P B.
@@ -202,6 +203,11 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 //            multipliers (in A below the diagonal), the row order (a snapshot of the row map) and
 //            a counter; roles 1..S each own a range of B's columns and apply the published panels
 //            to it (producer -> consumer only: role 0 never waits in this phase).
+//            Look-ahead (4 or more workgroups): role 0 applies panel j only to block j+1, the
+//            next panel's columns; roles 1..na (na = 1, or 2 from 6 workgroups on: columns left /
+//            right of 0.65 n) carry the rest of A's trailing columns and count their finished
+//            steps; role 0 waits for that block's helper to have finished step j-1 before it
+//            puts panel j there.  The other roles share B.
 //   back     when U and L^-1 P B are complete every role takes a range of columns of the
 //            truncated back substitution, cut so that the ranges cost the same.
 //   trace    X(c,c) goes to a scratch vector and the last workgroup to arrive adds it up in a
@@ -212,10 +218,11 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 // Waits are bounded: a time-out retires the matrix with info = EMME_EDEVICE instead of hanging.
 struct SplitCtl {
     int nwg;
+    int na;            // look-ahead: workgroups that carry A's trailing columns (0: none, 1, 2)
     int nitems;        // matrices of this launch: role = blockIdx.x / nitems
     const int* items;  // their indices in the batch (null: 0 .. nitems-1).  A dense list, so that
                        // the workgroups spread evenly over the XCDs (block i runs on XCD i % 8)
-    int* flags;     // [nbatch][4]: panels published | B ranges finished | arrivals | unused
+    int* flags;     // [nbatch][8]: panels published | helpers finished | arrivals | steps done by A-helper 1, 2
     int* rowmaps;   // [nbatch][nblk][n]  (nwg > 1 only)
     double2* diag;  // [nbatch][n]
 };
@@ -252,9 +259,12 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     if (active && active[b] == 0) return;
     const int nwg = SPLIT ? ctl.nwg : 1, S = nwg - 1;
     // look-ahead (4 or more workgroups): role 0 applies a panel only to the NEXT panel's columns,
-    // role 1 to the rest of A, so that A's trailing update leaves the factoring critical path
-    const bool la = SPLIT && ctl.nwg >= 4;
-    int* flag_pub = ctl.flags + 4 * b;  // the hand-over state is touched for SPLIT only
+    // roles 1..na to the rest of A (two of them: columns left / right of 0.65 n, equal work), so
+    // that A's trailing update leaves the factoring critical path
+    const int na = SPLIT ? ctl.na : 0;
+    const bool la = na > 0;
+    const int cA = na == 2 ? ((int)(0.65 * n) + 8) / 16 * 16 : n;  // first column of A-helper 2
+    int* flag_pub = ctl.flags + 8 * b;  // the hand-over state is touched for SPLIT only
     int* snap = ctl.rowmaps + (size_t)b * ((n + NB - 1) / NB) * n;
     double2* a = A + (size_t)b * n * n;
     double2* bb = B + (size_t)b * n * n;
@@ -302,10 +312,11 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     // ================= forward elimination, NB columns per step =======================
     if (SPLIT && role > 0) {
         // ---- roles 1..S: apply the published panels to B's columns f0 .. f1-1 ---------------
-        // (with look-ahead, role 1 instead carries A's trailing columns beyond the next panel
-        // and reports every finished step in flags[3]; roles 2..S share B)
-        const bool a_helper = la && role == 1;
-        const int hB = la ? S - 1 : S, rB = la ? role - 2 : role - 1;  // B helpers / this one's rank
+        // (with look-ahead, roles 1..na instead carry A's trailing columns beyond the next panel
+        // and report every finished step in flags[3], flags[4]; the others share B)
+        const bool a_helper = role <= na;
+        const int a_lo = role == 2 ? min(cA, n) : 0, a_hi = (na == 2 && role == 1) ? min(cA, n) : n;
+        const int hB = S - na, rB = role - na - 1;  // B helpers / this one's rank
         const int f0 = a_helper ? 0 : cut16((double)rB / hB);
         const int f1 = a_helper ? 0 : (rB == hB - 1 ? n : cut16((double)(rB + 1) / hB));
         for (int k0 = 0, kblk = 0; k0 < n; k0 += NB, ++kblk) {
@@ -314,27 +325,29 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             if (!wg_wait(flag_pub, kblk + 1)) return;
             for (int r = tid; r < nrem; r += BT) rowmap[k0 + r] = snap[(size_t)kblk * n + k0 + r];
             __syncthreads();
-            for (int e = tid; e < NB * NB; e += BT) {
-                const int kk = e / NB, c = e % NB;
-                L11[e] = (kk < nbk && c < kk) ? a[(size_t)rowmap[k0 + kk] * n + k0 + c]
-                                              : make_double2(0.0, 0.0);
-            }
-            for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
-                const int r = e / NB, c = e % NB;
-                panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c]
-                                            : make_double2(0.0, 0.0);
-            }
-            __syncthreads();
-            // this role's columns of [A | B] at this step
-            const int Jlo = a_helper ? min(n, k0 + nbk + NB) : n + f0;
-            const int Jhi = a_helper ? n : n + f1;
-            pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, Jlo, Jhi, wave, lane);
-            __syncthreads();
-            if (Jhi > Jlo)
+            // this role's columns of [A | B] at this step (an A-helper whose columns are all
+            // factored by now only keeps its row map up to date)
+            const int Jhi = a_helper ? a_hi : n + f1;
+            const int Jlo = a_helper ? min(Jhi, max(a_lo, k0 + nbk + NB)) : n + f0;
+            if (Jhi > Jlo) {  // uniform
+                for (int e = tid; e < NB * NB; e += BT) {
+                    const int kk = e / NB, c = e % NB;
+                    L11[e] = (kk < nbk && c < kk) ? a[(size_t)rowmap[k0 + kk] * n + k0 + c]
+                                                  : make_double2(0.0, 0.0);
+                }
+                for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+                    const int r = e / NB, c = e % NB;
+                    panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c]
+                                                : make_double2(0.0, 0.0);
+                }
+                __syncthreads();
+                pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, Jlo, Jhi, wave, lane);
+                __syncthreads();
                 mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, Jlo, Jhi - Jlo, wave, lane);
+            }
             __syncthreads();  // (every thread's stores are performed; thread 0 releases them)
             if (a_helper && tid == 0)
-                __hip_atomic_store(flag_pub + 3, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flag_pub + 2 + role, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else
     for (int k0 = 0; k0 < n; k0 += NB) {
@@ -457,8 +470,8 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         const int lane = tid_t & 63, wave = SPLIT ? __builtin_amdgcn_readfirstlane(tid_t >> 6) : tid_t >> 6;
         const int J0 = k0 + nbk;              // first trailing column of A
         if (SPLIT && la && k0 > 0 && J0 < n) {
-            // panel j goes onto block j+1 after role 1 has put panels 0 .. j-1 there
-            if (!wg_wait(flag_pub + 3, k0 / NB)) return;
+            // panel j goes onto block j+1 after that block's A-helper has put panels 0 .. j-1 there
+            if (!wg_wait(flag_pub + (J0 >= cA ? 4 : 3), k0 / NB)) return;
         }
         // trailing A columns (+ all of B without helpers; the next panel's only with look-ahead)
         const int Jend = SPLIT ? (la ? min(n, J0 + NB) : n) : 2 * n;
@@ -619,7 +632,7 @@ size_t trace_solve_blocked_lds(int n) {
 
 size_t trace_solve_blocked_scratch(int n, int nbatch) {
     const size_t nblk = (size_t)(n + NB - 1) / NB;
-    return (size_t)nbatch * (4 * sizeof(int) + nblk * n * sizeof(int) + (size_t)n * sizeof(double2)) + 256;
+    return (size_t)nbatch * (8 * sizeof(int) + nblk * n * sizeof(int) + (size_t)n * sizeof(double2)) + 256;
 }
 
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
@@ -638,13 +651,14 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
     // scratch: diag | flags | row-map snapshots
     SplitCtl ctl;
     ctl.nwg = nwg;
+    ctl.na = nwg >= 6 ? 2 : (nwg >= 4 ? 1 : 0);
     ctl.items = items;
     ctl.nitems = items ? nitems : nbatch;
     ctl.diag = (double2*)scratch;
     ctl.flags = (int*)(ctl.diag + (size_t)nbatch * n);
-    ctl.rowmaps = ctl.flags + 4 * (size_t)nbatch;
+    ctl.rowmaps = ctl.flags + 8 * (size_t)nbatch;
     if (nwg > 1) {
-        hipError_t e = hipMemsetAsync(ctl.flags, 0, 4 * sizeof(int) * (size_t)nbatch, stream);
+        hipError_t e = hipMemsetAsync(ctl.flags, 0, 8 * sizeof(int) * (size_t)nbatch, stream);
         if (e != hipSuccess) return e;
     }
     if (nwg > 1) {

@@ -272,11 +272,13 @@ def test_trace_solve_sizes_against_lapack(emme, n):
         assert abs(tr[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, tr[b], want)
 
 
-@pytest.mark.parametrize("n,nwg", [(256, 2), (256, 4), (200, 3), (130, 2), (37, 2), (512, 4), (16, 8)])
+@pytest.mark.parametrize("n,nwg", [(256, 2), (256, 4), (200, 3), (130, 2), (37, 2), (512, 4), (16, 8),
+                                   (256, 6), (200, 7), (512, 8), (100, 5)])
 def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
     """The LU with 1 + S workgroups per matrix (role 0 factors A, the others carry B's columns,
-    all share the back substitution): bit-identical to the one-workgroup launch, incl. ragged
-    sizes, an inactive-looking singular neighbour and sizes below one panel per helper."""
+    all share the back substitution; from 4 workgroups on with look-ahead: one or two of them
+    carry A's trailing columns): bit-identical to the one-workgroup launch, incl. ragged
+    sizes, a singular neighbour and sizes below one panel per helper."""
     rng = np.random.default_rng(1000 * n + nwg)
     nb = 5
     A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
