@@ -622,6 +622,15 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         const int nchunks = (int)ch.size() / 2;
         const int n_lane = (int)idx.size();
         L.items_per_group = union_walk ? 3 : items_per_group_for(c, nchunks > 0 ? nchunks : 1);
+        if (union_walk) {
+            // up to three chunks (late Newton steps: <= 48 omegas) leave the SIMDs short of waves
+            // with three items per group: two then (measured: one is worse again -- every
+            // workgroup stages the grid tables; EMME_UNION_IPG_FEW / EMME_UNION_FEW_CHUNKS)
+            const char* e1 = std::getenv("EMME_UNION_IPG_FEW");
+            const char* e2 = std::getenv("EMME_UNION_FEW_CHUNKS");
+            const int ipg_few = e1 ? std::atoi(e1) : 2, few = e2 ? std::atoi(e2) : 3;
+            if (nchunks <= few) L.items_per_group = std::max(1, ipg_few);
+        }
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_lane, hipMemcpyHostToDevice, c->stream));
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
