@@ -94,6 +94,7 @@ struct emme_ctx {
     size_t lu_scratch_bytes = 0;
     int n_cu = 256;                // compute units of the device
     int last_lu_nwg = 1;           // workgroups per matrix of the last LU launch
+    bool lu_one_wg = false;        // a hand-over of the multi-workgroup LU timed out once: never again
     bool ext_failed = false;
     unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
     double cache_bytes_used = 0.0;
@@ -317,7 +318,9 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
             if (n_live == 0) return hipSuccess;
         }
         int nwg = 1;
-        if (split_env > 0) {
+        if (c->lu_one_wg) {
+            nwg = 1;
+        } else if (split_env > 0) {
             nwg = std::min(split_env, 16);
         } else if (n >= 128) {
             // every workgroup of a matrix must be resident at once (they wait for each other):
@@ -1193,6 +1196,19 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         // per item (the reference would carry the NaN to its "eigenvalue": "NaN" record,
         // src/main.cpp:311-316); the other chains of the batch are unaffected
         if (stv[b] != 0 && info[b] == 0) info[b] = EMME_ENUMERIC;
+    }
+    // The multi-workgroup LU needs its workgroups resident together; if something else held
+    // compute units for seconds (a foreign kernel on a shared device) a hand-over wait timed out
+    // and retired those chains with EMME_EDEVICE.  Do the search again with one workgroup per
+    // matrix, and keep it that way for this context.
+    if (!c->lu_one_wg) {
+        bool timed_out = false;
+        for (int b = 0; b < n; ++b) timed_out |= info[b] == EMME_EDEVICE;
+        if (timed_out) {
+            c->lu_one_wg = true;
+            if (std::getenv("EMME_DEBUG")) fprintf(stderr, "[emme] LU hand-over timed out: repeating the search with one workgroup per matrix\n");
+            return emme_solve_roots(c, guesses, n, tol, step_limit, roots, iters, info, iterates);
+        }
     }
     return EMME_OK;
 }

@@ -219,6 +219,7 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 struct SplitCtl {
     int nwg;
     int na;            // look-ahead: workgroups that carry A's trailing columns (0: none, 1, 2)
+    int spin_limit;    // polls before a hand-over wait gives up (EMME_LU_SPIN_LIMIT; tests use 1)
     int nitems;        // matrices of this launch: role = blockIdx.x / nitems
     const int* items;  // their indices in the batch (null: 0 .. nitems-1).  A dense list, so that
                        // the workgroups spread evenly over the XCDs (block i runs on XCD i % 8)
@@ -227,13 +228,13 @@ struct SplitCtl {
     double2* diag;  // [nbatch][n]
 };
 constexpr int ABORT = 1 << 30;
-constexpr long SPIN_LIMIT = 16000000;  // about 4 s
+constexpr int SPIN_LIMIT = 16000000;  // about 4 s
 constexpr int INFO_TIMEOUT = -3;  // EMME_EDEVICE
 
-__device__ __forceinline__ int spin_ge(int* p, int v) {
+__device__ __forceinline__ int spin_ge(int* p, int v, int limit) {
     // relaxed polling (an acquire load would invalidate the XCD's L2 on every trip), one
     // acquire fence once the value is there
-    for (long it = 0; it < SPIN_LIMIT; ++it) {
+    for (int it = 0; it < limit; ++it) {
         const int x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (x >= v) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
 
     // whole-workgroup wait for *flag >= v; false on abort / time-out (the matrix is retired)
     auto wg_wait = [&](int* flag, int v) -> bool {
-        if (tid == 0) sh.go = spin_ge(flag, v);
+        if (tid == 0) sh.go = spin_ge(flag, v, ctl.spin_limit);
         __syncthreads();
         const int g = sh.go;
         __syncthreads();
@@ -652,6 +653,10 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
     SplitCtl ctl;
     ctl.nwg = nwg;
     ctl.na = nwg >= 6 ? 2 : (nwg >= 4 ? 1 : 0);
+    {
+        const char* e = std::getenv("EMME_LU_SPIN_LIMIT");
+        ctl.spin_limit = e ? std::max(1, std::atoi(e)) : SPIN_LIMIT;
+    }
     ctl.items = items;
     ctl.nitems = items ? nitems : nbatch;
     ctl.diag = (double2*)scratch;

@@ -316,6 +316,33 @@ def test_trace_solve_split_falls_back_when_the_grid_cannot_be_resident(emme, mon
     assert np.array_equal(tr1.view(np.float64), tr4.view(np.float64))
 
 
+def test_lu_hand_over_time_out_is_bounded_and_repaired(emme, monkeypatch):
+    """A helper workgroup that gives up waiting (here: after ONE poll) retires its matrix with
+    EMME_EDEVICE instead of hanging; a direct call reports that per item, a root search repeats
+    itself with one workgroup per matrix and returns the same bits as if it had never split."""
+    rng = np.random.default_rng(11)
+    n, nb = 64, 6
+    A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n)) + 4.0 * np.eye(n)
+    B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    d = example_tokamak(npoints=64)
+    guesses = np.array([-0.8 + 0.25j, -0.7 + 0.3j, -0.9 + 0.2j])
+    with _ctx(emme, d) as ctx:
+        ctx.solve_roots(guesses)
+        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        tr1, info1 = ctx.trace_solve(A, B)
+        r1, it1, i1 = ctx.solve_roots(guesses)
+        monkeypatch.setenv("EMME_LU_SPLIT", "3")
+        monkeypatch.setenv("EMME_LU_SPIN_LIMIT", "1")
+        tr3, info3 = ctx.trace_solve(A, B)
+        assert set(np.unique(info3)) <= {0, -3}  # EMME_EDEVICE
+        ok = info3 == 0
+        assert np.array_equal(tr1[ok].view(np.float64), tr3[ok].view(np.float64))
+        assert np.isnan(tr3[~ok].real).all()
+        r3, it3, i3 = ctx.solve_roots(guesses)
+    assert (i1 == 0).all() and np.array_equal(i1, i3) and np.array_equal(it1, it3)
+    assert np.array_equal(r1.view(np.float64), r3.view(np.float64))
+
+
 @pytest.mark.parametrize("nwg", [2, 3])
 def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
     """Whole Newton searches with 1 and with several LU workgroups per matrix: same iterates,
