@@ -87,7 +87,7 @@ struct emme_ctx {
     bool folded = true;        // records carry exp(A0); exp(T omega) comes from a per-launch phase table
     void* d_etab = nullptr;    // phase table of the current launch
     size_t etab_bytes = 0;
-    std::vector<int> h_lu_items;   // blocked LU: the live matrices of the launch (host / device)
+    int* h_lu_items = nullptr;     // blocked LU: the live matrices of the launch (pinned host / device)
     int* d_lu_items = nullptr;
     int lu_items_cap = 0;
     void* d_lu_scratch = nullptr;  // blocked LU: diagonal of X, hand-over flags, row-map snapshots
@@ -95,6 +95,9 @@ struct emme_ctx {
     int n_cu = 256;                // compute units of the device
     int last_lu_nwg = 1;           // workgroups per matrix of the last LU launch
     bool lu_one_wg = false;        // a hand-over of the multi-workgroup LU timed out once: never again
+    int* p_act = nullptr;          // pinned host copies of d_active / d_intervals: the Newton loop
+    unsigned long long* p_iv = nullptr;  // fetches them without a stream synchronisation of its own
+    int p_cap = 0;
     bool ext_failed = false;
     unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
     double cache_bytes_used = 0.0;
@@ -311,10 +314,19 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
         // dense list of the live matrices (h_active: host copy of `active`, null = all live)
         int n_live = nbatch;
         if (h_active) {
-            c->h_lu_items.clear();
+            if (nbatch > c->lu_items_cap) {
+                if (c->d_lu_items) (void)hipFree(c->d_lu_items);
+                if (c->h_lu_items) (void)hipHostFree(c->h_lu_items);
+                c->d_lu_items = nullptr, c->h_lu_items = nullptr, c->lu_items_cap = 0;
+                hipError_t e = hipMalloc((void**)&c->d_lu_items, sizeof(int) * nbatch);
+                // pinned: the upload must not wait for the work queued on the stream
+                if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_lu_items, sizeof(int) * nbatch);
+                if (e != hipSuccess) return e;
+                c->lu_items_cap = nbatch;
+            }
+            n_live = 0;
             for (int b = 0; b < nbatch; ++b)
-                if (h_active[b]) c->h_lu_items.push_back(b);
-            n_live = (int)c->h_lu_items.size();
+                if (h_active[b]) c->h_lu_items[n_live++] = b;
             if (n_live == 0) return hipSuccess;
         }
         int nwg = 1;
@@ -332,14 +344,7 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
         c->last_lu_nwg = nwg;
         const int* d_items = nullptr;
         if (nwg > 1 && h_active) {
-            if (nbatch > c->lu_items_cap) {
-                if (c->d_lu_items) (void)hipFree(c->d_lu_items);
-                c->d_lu_items = nullptr, c->lu_items_cap = 0;
-                hipError_t e = hipMalloc((void**)&c->d_lu_items, sizeof(int) * nbatch);
-                if (e != hipSuccess) return e;
-                c->lu_items_cap = nbatch;
-            }
-            hipError_t e = hipMemcpyAsync(c->d_lu_items, c->h_lu_items.data(), sizeof(int) * n_live,
+            hipError_t e = hipMemcpyAsync(c->d_lu_items, c->h_lu_items, sizeof(int) * n_live,
                                           hipMemcpyHostToDevice, c->stream);
             if (e != hipSuccess) return e;
             d_items = c->d_lu_items;
@@ -820,6 +825,9 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     F(c->d_etab);
     F(c->d_lu_scratch);
     F(c->d_lu_items);
+    if (c->h_lu_items) (void)hipHostFree(c->h_lu_items);
+    if (c->p_act) (void)hipHostFree(c->p_act);
+    if (c->p_iv) (void)hipHostFree(c->p_iv);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -1126,6 +1134,45 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
 
     rc = refresh_cost();
     if (rc) return rc;
+    if (n > c->p_cap) {
+        if (c->p_act) (void)hipHostFree(c->p_act);
+        if (c->p_iv) (void)hipHostFree(c->p_iv);
+        c->p_act = nullptr, c->p_iv = nullptr, c->p_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->p_act, sizeof(int) * n));
+        HIP_TRY(hipHostMalloc((void**)&c->p_iv, sizeof(unsigned long long) * n));
+        c->p_cap = n;
+    }
+    // One stream synchronisation per Newton step: the host needs the new omegas (contour
+    // classes, cache growth) before it can launch the fill.  The active flags and interval
+    // counts a fill leaves behind travel to pinned memory asynchronously and are read after the
+    // NEXT step's synchronisation, so the LU and the update of that step are queued behind the
+    // fill without a bubble (their list of live matrices is one step old: a superset).
+    bool pending = false;
+    int j_pending = 0;
+    auto take_pending = [&]() {  // results of the previous step's fill + retire
+        for (int b = 0; b < n; ++b) {
+            act[b] = c->p_act[b];
+            iv_now[b] = c->p_iv[b];
+            if (iv_now[b] != iv_prev[b]) cost[b] = iv_now[b] - iv_prev[b];
+            iv_prev[b] = iv_now[b];
+        }
+        pending = false;
+        if (std::getenv("EMME_DEBUG")) {
+            unsigned long long tot = 0, mx = 0;
+            int na = 0, nprev = 0;
+            for (int b = 0; b < n; ++b) {
+                if (iv_now[b] != iv_prev_dbg[b]) {
+                    const unsigned long long d = iv_now[b] - iv_prev_dbg[b];
+                    tot += d, mx = d > mx ? d : mx, ++nprev;
+                }
+                iv_prev_dbg[b] = iv_now[b];
+                na += act[b] != 0;
+            }
+            fprintf(stderr, "[emme] LU workgroups per matrix %d\n", c->last_lu_nwg);
+            fprintf(stderr, "[emme] iter %2d: assembled %3d, lane-intervals %10llu (max/item %9llu), still active %d\n",
+                    j_pending, nprev, tot, mx, na);
+        }
+    };
     for (int j = 0; j <= step_limit; ++j) {  // src/main.cpp:43
         const bool fused_copy = method == EMME_METHOD_TRACE_SECANT;
         {
@@ -1147,6 +1194,12 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         }
         HIP_TRY(hipMemcpyAsync(h_w.data(), c->d_omega, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (pending) {
+            take_pending();
+            bool any = false;
+            for (int b = 0; b < n; ++b) any |= act[b] != 0;
+            if (!any) break;  // (this step's LU and update found nothing active: no-ops)
+        }
         rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
                          cost.data(), h_w.data());
         if (rc) return rc;
@@ -1154,30 +1207,9 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(launch_retire(n, c->d_active, c->stream));
         }
-        HIP_TRY(hipMemcpyAsync(act.data(), c->d_active, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-        rc = refresh_cost();  // also synchronises the stream
-        if (rc) return rc;
-        if (std::getenv("EMME_DEBUG")) {
-            static unsigned long long last_rounds = 0;
-            unsigned long long r = 0, tot = 0, mx = 0;
-            (void)hipMemcpy(&r, c->d_rounds, sizeof r, hipMemcpyDeviceToHost);
-            int na = 0, nprev = 0;
-            for (int b = 0; b < n; ++b) {
-                if (iv_now[b] != iv_prev_dbg[b]) {
-                    const unsigned long long d = iv_now[b] - iv_prev_dbg[b];
-                    tot += d, mx = d > mx ? d : mx, ++nprev;
-                }
-                iv_prev_dbg[b] = iv_now[b];
-                na += act[b] != 0;
-            }
-            fprintf(stderr, "[emme] LU workgroups per matrix %d\n", c->last_lu_nwg);
-            fprintf(stderr, "[emme] iter %2d: assembled %3d, lane-intervals %10llu (max/item %9llu), rounds %9llu, fill %.3f, still active %d\n",
-                    j, nprev, tot, mx, r - last_rounds, tot / (16.0 * (double)(r - last_rounds + 1)), na);
-            last_rounds = r;
-        }
-        bool any = false;
-        for (int b = 0; b < n; ++b) any |= act[b] != 0;
-        if (!any) break;
+        HIP_TRY(hipMemcpyAsync(c->p_act, c->d_active, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->p_iv, c->d_intervals, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+        pending = true, j_pending = j;
     }
     std::vector<unsigned long long> iv(n);
     std::vector<int> stv(n);
