@@ -115,7 +115,10 @@ int emme_newton_step_batch(emme_ctx_t* ctx, double* omega, double* domega, int n
                            double* M, double* Mp, int method, int* info);
 
 /* tr(A_b^-1 B_b) for b < nbatch by partial-pivot LU (A, B: nbatch*n*n complex, destroyed;
- * host or device).  tr: 2*nbatch doubles (host). info: nbatch ints (host). */
+ * host or device).  tr: 2*nbatch doubles (host). info: nbatch ints (host): 0, k > 0 = U(k,k)
+ * exactly zero (tr[b] = NaN), or EMME_EDEVICE if the cooperating workgroups of that matrix
+ * gave up waiting for each other (only when something else holds compute units for seconds;
+ * emme_solve_roots repairs that case itself, the step-level calls report it). */
 int emme_trace_solve_batch(emme_ctx_t* ctx, int n, int nbatch, double* A, double* B, double* tr,
                            int* info);
 
