@@ -327,7 +327,8 @@ def test_lu_hand_over_time_out_is_bounded_and_repaired(emme, monkeypatch):
     d = example_tokamak(npoints=64)
     guesses = np.array([-0.8 + 0.25j, -0.7 + 0.3j, -0.9 + 0.2j])
     with _ctx(emme, d) as ctx:
-        ctx.solve_roots(guesses)
+        for _ in range(3):  # node cache built and settled
+            ctx.solve_roots(guesses)
         monkeypatch.setenv("EMME_LU_SPLIT", "1")
         tr1, info1 = ctx.trace_solve(A, B)
         r1, it1, i1 = ctx.solve_roots(guesses)
@@ -351,7 +352,8 @@ def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
     d = example_tokamak(npoints=64)
     guesses = np.array([-0.8 + 0.25j, -0.7 + 0.3j, -0.9 + 0.2j, -0.6 + 0.1j, -1.0 + 0.35j])
     with _ctx(emme, d) as ctx:
-        ctx.solve_roots(guesses)  # builds the node cache: later fills are identical
+        for _ in range(3):  # builds the node cache and lets it settle: later fills are identical
+            ctx.solve_roots(guesses)
         monkeypatch.setenv("EMME_LU_SPLIT", "1")
         r1, it1, info1, its1 = ctx.solve_roots(guesses, want_iterates=True)
         monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
@@ -406,6 +408,34 @@ def test_every_fill_kernel_matches_oracle(emme, oracle, mode, monkeypatch):
             # (interval count) must still be identical
             tol = 1e-6 if w == -0.142 - 1.469j else TOL_M
             assert np.abs(M[k] - Mo).max() <= tol * np.abs(Mo).max(), (mode, d["conf"], w)
+
+
+def test_union_fill_bits_do_not_depend_on_intervals_per_round(emme, monkeypatch):
+    """The union-walk kernel serving one or two intervals per round (and two or three items per
+    lane group): a lane needs only its own next key, so every omega's matrix and interval count
+    are the same bit for bit -- also for omegas whose trees barely overlap."""
+    monkeypatch.setenv("EMME_NODE_CACHE_GB", "8")
+    monkeypatch.setenv("EMME_WL_MIN", "1")
+    d = example_tokamak(npoints=48)
+    rng = np.random.default_rng(3)
+    ws = np.concatenate([rng.uniform(-1.2, -0.4, 20) + 1j * rng.uniform(0.05, 0.4, 20),
+                         [-0.142 - 1.469j, 0.153 - 0.316j, 4.591 - 3.987j, -0.35 - 0.788j, 0.6 + 0.1j]])
+    with _ctx(emme, d) as ctx:
+        # builds the cache and lets it grow to its final shape (a fill that deferred integrals
+        # makes the next one cache a subtree around them, at most NODE_CACHE_MAX_SUB times; an
+        # integral that moves from the cooperative kernel to the cached path changes its rounding)
+        for _ in range(8):
+            ctx.assemble(ws)
+        monkeypatch.setenv("EMME_UNION_SEL", "1")
+        M1, iv1 = ctx.assemble(ws, want_intervals=True)
+        monkeypatch.setenv("EMME_UNION_SEL", "2")
+        M2, iv2 = ctx.assemble(ws, want_intervals=True)
+        monkeypatch.setenv("EMME_UNION_IPG_FEW", "3")
+        M3, iv3 = ctx.assemble(ws, want_intervals=True)
+        assert ctx.fill_kernel().startswith("k_assemble_union")
+    assert np.array_equal(iv1, iv2) and np.array_equal(iv1, iv3)
+    assert np.array_equal(M1.view(np.float64), M2.view(np.float64), equal_nan=True)
+    assert np.array_equal(M1.view(np.float64), M3.view(np.float64), equal_nan=True)
 
 
 @pytest.mark.parametrize("mode", ["cached", "cached-independent", "cached-unfolded", "omega-lane", "nodes"])
