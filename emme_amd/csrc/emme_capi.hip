@@ -302,7 +302,10 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
     static const bool force_unblocked = std::getenv("EMME_LU_UNBLOCKED") != nullptr;
     const char* split_s = std::getenv("EMME_LU_SPLIT");  // read per call: the tests switch it
     const int split_env = split_s ? std::atoi(split_s) : 0;
-    if (!force_unblocked && trace_solve_blocked_lds(n) <= 150 * 1024) {
+    // n <= ~560: the whole L21 panel fits in LDS; up to 1024 the chunked build takes over, which
+    // needs helper workgroups (>= 2 per matrix, all resident); otherwise the unblocked kernel
+    const bool fits = trace_solve_blocked_lds(n) <= 150 * 1024;
+    if (!force_unblocked && (fits || n <= 1024)) {
         const size_t need = trace_solve_blocked_scratch(n, nbatch);
         if (need > c->lu_scratch_bytes) {
             if (c->d_lu_scratch) (void)hipFree(c->d_lu_scratch);
@@ -341,6 +344,7 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
             // (n = 256: four are enough, role 0 is the limit then; n = 512: two A-helpers pay)
             nwg = std::max(1, std::min(n >= 384 ? 8 : 4, c->n_cu / n_live));
         }
+        if (!fits && nwg < 2 && !c->lu_one_wg && split_env != 1) nwg = 2;
         c->last_lu_nwg = nwg;
         const int* d_items = nullptr;
         if (nwg > 1 && h_active) {
@@ -349,8 +353,11 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
             if (e != hipSuccess) return e;
             d_items = c->d_lu_items;
         }
-        return launch_trace_solve_blocked(n, nbatch, A, B, active, tr, info, nwg, d_items, n_live,
-                                          c->d_lu_scratch, c->stream);
+        const hipError_t e = launch_trace_solve_blocked(n, nbatch, A, B, active, tr, info, nwg, d_items, n_live,
+                                                        c->d_lu_scratch, c->stream);
+        if (e != hipErrorNotSupported) return e;
+        (void)hipGetLastError();  // chunked build not possible here (one workgroup per matrix, or no room)
+        c->last_lu_nwg = 1;
     }
     return launch_trace_solve(n, nbatch, A, B, active, tr, info, c->stream);
 }

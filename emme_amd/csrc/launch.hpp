@@ -98,6 +98,8 @@ hipError_t launch_copy_active(int n, int nbatch, const double* src, double* dst1
 // columns; `items` = device list of the nitems matrices to work on, null for all of them);
 // `scratch` holds trace_solve_blocked_scratch(n, nbatch) bytes.
 size_t trace_solve_blocked_lds(int n);
+size_t trace_solve_chunked_lds(int n);  // 560 < n <= 1024: panel rows in chunks (helper workgroups required;
+                                        // the launcher returns hipErrorNotSupported when it cannot)
 size_t trace_solve_blocked_scratch(int n, int nbatch);
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
                                       double* tr, int* info, int nwg, const int* items, int nitems,

@@ -91,14 +91,15 @@ struct BlkShared {
 //   A      : LDS `panel`, row (logical row - crow0), rows LS entries apart
 //   B rows : logical rows brow0 .. brow0 + nbk - 1, read from memory once per column tile
 //   cols   : columns col0 .. col0 + ncols - 1 of the augmented matrix [a | bb]
-//   LOWER  : only tiles that contain an entry with (row - crow0) >= (col - col0) are touched
+//   LOWER  : only tiles that contain an entry with (row - crow0) + 16 rt_shift >= (col - col0) are touched
 // The inner loop is branch-free: out-of-range rows / columns are clamped to valid addresses for
 // the loads (their operands are zeroed, their results never stored), so a tile is 4 LDS index
 // reads, 4 LDS operand reads, 4 loads, 16 MFMAs, 4 stores.
 template <bool LOWER>
 __device__ __forceinline__ void mfma_update(int n, double2* a, double2* bb, const int* rowmap,
                                             const double2* panel, int crow0, int nrows, int brow0,
-                                            int nbk, int col0, int ncols, int wave, int lane) {
+                                            int nbk, int col0, int ncols, int wave, int lane,
+                                            int rt_shift = 0) {
     const int nrt = (nrows + 15) >> 4, nct = (ncols + 15) >> 4;
     const int i16 = lane & 15, kq = lane >> 4;
     int cur_ct = -1;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void mfma_update(int n, double2* a, double2* bb, cons
     bool okc = false;
     for (int tile = wave; tile < nrt * nct; tile += BW) {
         const int ct = tile / nrt, rt = tile - ct * nrt;
-        if (LOWER && ct > rt) continue;  // wave-uniform
+        if (LOWER && ct > rt + rt_shift) continue;  // wave-uniform (rt_shift: row tiles the C rows start below the columns)
         if (ct != cur_ct) {              // wave-uniform
             cur_ct = ct;
             const int J = col0 + ct * 16 + i16;
@@ -245,7 +246,11 @@ __device__ __forceinline__ int spin_ge(int* p, int v, int limit) {
     return -1;
 }
 
-template <bool SPLIT>
+// CHUNK (with SPLIT only): matrices whose L21 panel does not fit in LDS (560 < n <= 1024).  The
+// multipliers then go from the panel registers straight to global memory and every trailing /
+// back-substitution update walks the rows in chunks of RC, fetching that chunk's panel rows.
+constexpr int RC = 512;
+template <bool SPLIT, bool CHUNK = false>
 __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, double2* A, double2* B,
                                                             const int* active, double2* tr_out,
                                                             int* info_out, SplitCtl ctl) {
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     extern __shared__ double2 lds2[];
     __shared__ BlkShared sh;
 
+    static_assert(SPLIT || !CHUNK, "the chunked panel needs the multipliers in global memory");
     const int role = SPLIT ? blockIdx.x / ctl.nitems : 0;
     int b = blockIdx.x - role * ctl.nitems;
     if (SPLIT && ctl.items) b = ctl.items[b];
@@ -310,6 +316,22 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         return c < n ? c : n;
     };
 
+    // X(rows below block k0, columns Jlo ..) -= L21 * U12 with the panel rows fetched from A in
+    // chunks of RC rows (CHUNK builds; the row map already holds the new order)
+    auto t2_chunked = [&](int k0, int nbk, int nrem, int Jlo, int ncols, int wave_, int lane_) {
+        for (int r0 = 0; r0 < nrem - nbk; r0 += RC) {
+            const int nr = min(RC, nrem - nbk - r0);
+            for (int e = tid; e < nr * NB; e += BT) {
+                const int r = e / NB, c = e % NB;
+                panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r0 + r] * n + k0 + c]
+                                            : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk + r0, nr, k0, nbk, Jlo, ncols, wave_, lane_);
+            __syncthreads();
+        }
+    };
+
     // ================= forward elimination, NB columns per step =======================
     if (SPLIT && role > 0) {
         // ---- roles 1..S: apply the published panels to B's columns f0 .. f1-1 ---------------
@@ -336,15 +358,20 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                     L11[e] = (kk < nbk && c < kk) ? a[(size_t)rowmap[k0 + kk] * n + k0 + c]
                                                   : make_double2(0.0, 0.0);
                 }
-                for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
-                    const int r = e / NB, c = e % NB;
-                    panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c]
-                                                : make_double2(0.0, 0.0);
+                if (!CHUNK) {
+                    for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+                        const int r = e / NB, c = e % NB;
+                        panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c]
+                                                    : make_double2(0.0, 0.0);
+                    }
                 }
                 __syncthreads();
                 pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, Jlo, Jhi, wave, lane);
                 __syncthreads();
-                mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, Jlo, Jhi - Jlo, wave, lane);
+                if (CHUNK)
+                    t2_chunked(k0, nbk, nrem, Jlo, Jhi - Jlo, wave, lane);
+                else
+                    mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, Jlo, Jhi - Jlo, wave, lane);
             }
             __syncthreads();  // (every thread's stores are performed; thread 0 releases them)
             if (a_helper && tid == 0)
@@ -438,9 +465,15 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                     before += pivof[t] >= 0;
                 }
                 pos = nbk + (tid - before);
+                if (CHUNK) {  // straight to A: the panel does not fit in LDS
 #pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    panel[(pos - nbk) * LS + c] = make_double2(pr[c].x, pr[c].y);
+                    for (int c = 0; c < NB; ++c)
+                        if (c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                        panel[(pos - nbk) * LS + c] = make_double2(pr[c].x, pr[c].y);
+                }
             }
             rowmap[k0 + pos] = myrow;
         }
@@ -455,9 +488,11 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                 const int kk = e / NB, c = e % NB;
                 if (kk < nbk && c < kk) a[(size_t)rowmap[k0 + kk] * n + k0 + c] = L11[e];
             }
-            for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
-                const int r = e / NB, c = e % NB;
-                if (c < nbk) a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] = panel[r * LS + c];
+            if (!CHUNK) {
+                for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+                    const int r = e / NB, c = e % NB;
+                    if (c < nbk) a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] = panel[r * LS + c];
+                }
             }
             __syncthreads();  // every thread's stores are performed; thread 0 releases them
             if (tid == 0)
@@ -504,7 +539,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         }
         __syncthreads();
         // T2: X(rows below the block, trailing columns) -= L21 * U12 on the matrix cores
-        if (!SPLIT || ncols > 0)
+        if (CHUNK) {
+            if (ncols > 0) t2_chunked(k0, nbk, nrem, J0, ncols, wave, lane);
+        } else if (!SPLIT || ncols > 0)
             mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nrem - nbk, k0, nbk, J0, ncols, wave, lane);
         __syncthreads();
     }
@@ -552,9 +589,11 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             }
             L11[e] = v;
         }
-        for (int e = tid; e < (k0 - c0) * NB; e += BT) {  // rows c0 .. k0-1 (none if k0 <= c0)
-            const int rr = e / NB, c = e % NB;
-            panel[rr * LS + c] = c < nbk ? *(&a[(size_t)rowmap[c0 + rr] * n + k0 + c]) : make_double2(0.0, 0.0);
+        if (!CHUNK) {
+            for (int e = tid; e < (k0 - c0) * NB; e += BT) {  // rows c0 .. k0-1 (none if k0 <= c0)
+                const int rr = e / NB, c = e % NB;
+                panel[rr * LS + c] = c < nbk ? *(&a[(size_t)rowmap[c0 + rr] * n + k0 + c]) : make_double2(0.0, 0.0);
+            }
         }
         __syncthreads();
         const int ncols = live - c0;
@@ -595,7 +634,19 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         __syncthreads();
         // rows above the block: C(rr, c) -= sum_k U(rr, k0+k) X(k0+k, c), needed for rr >= c only
         // (column tiles right of the row tile are skipped)
-        if (k0 > c0)
+        if (CHUNK) {
+            // the U column block in chunks of RC rows (c0 and RC are multiples of 16)
+            for (int r0 = c0; r0 < k0; r0 += RC) {
+                const int nr = min(RC, k0 - r0);
+                for (int e = tid; e < nr * NB; e += BT) {
+                    const int rr = e / NB, c = e % NB;
+                    panel[rr * LS + c] = c < nbk ? a[(size_t)rowmap[r0 + rr] * n + k0 + c] : make_double2(0.0, 0.0);
+                }
+                __syncthreads();
+                mfma_update<true>(n, a, bb, rowmap, panel, r0, nr, k0, nbk, n + c0, ncols, wave, lane, (r0 - c0) / 16);
+                __syncthreads();
+            }
+        } else if (k0 > c0)
             mfma_update<true>(n, a, bb, rowmap, panel, c0, k0 - c0, k0, nbk, n + c0, ncols, wave, lane);
         __syncthreads();
     }
@@ -627,6 +678,12 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
 
 }  // namespace
 
+// LDS of the chunked build (560 < n <= 1024): the panel holds RC rows at a time
+size_t trace_solve_chunked_lds(int n) {
+    const int rows = n < RC ? n : RC;
+    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)rows * LS) * sizeof(double2);
+}
+
 size_t trace_solve_blocked_lds(int n) {
     return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)n * LS) * sizeof(double2);
 }
@@ -639,12 +696,18 @@ size_t trace_solve_blocked_scratch(int n, int nbatch) {
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
                                       double* tr, int* info, int nwg, const int* items, int nitems,
                                       void* scratch, hipStream_t stream) {
-    const size_t lds = trace_solve_blocked_lds(n);
+    // matrices whose whole L21 panel does not fit in LDS go through the chunked build, which
+    // exists only with helper workgroups (the multipliers must be in global memory anyway)
+    const bool chunk = trace_solve_blocked_lds(n) > 150 * 1024;
+    if (chunk && (n > BT || nwg < 2)) return hipErrorNotSupported;
+    const size_t lds = chunk ? trace_solve_chunked_lds(n) : trace_solve_blocked_lds(n);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set = true;
     }
@@ -678,8 +741,9 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         if (hipGetDevice(&dev) != hipSuccess) dev = -1;
         if (dev < 0 || dev != cap_dev || lds != cap_lds) {
             int per_cu = 0, ncu = 0;
-            if (dev < 0 ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds) != hipSuccess ||
+            hipError_t eo = chunk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true, true>, BT, lds)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds);
+            if (dev < 0 || eo != hipSuccess ||
                 hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
                 (void)hipGetLastError();
                 per_cu = 0;
@@ -687,10 +751,15 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
             cap = (long)per_cu * ncu, cap_dev = dev, cap_lds = lds;
         }
         if (cap >= (long)ctl.nitems * nwg) {
-            hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
-                               n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+            if (chunk)
+                hipLaunchKernelGGL((k_trace_solve_blocked<true, true>), dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
+                                   n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+            else
+                hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
+                                   n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
             return hipGetLastError();
         }
+        if (chunk) return hipErrorNotSupported;
         ctl.nwg = 1;
     }
     hipLaunchKernelGGL(k_trace_solve_blocked<false>, dim3(nbatch), dim3(BT), lds, stream, n, nbatch,
