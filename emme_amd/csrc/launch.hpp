@@ -93,7 +93,7 @@ hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int
 hipError_t launch_copy_active(int n, int nbatch, const double* src, double* dst1, double* dst2,
                               const int* active, hipStream_t stream);
 
-// Blocked version (linstep_blocked.hip); usable while its LDS panel fits (n <= ~560).
+// Blocked version (linstep_blocked.hip): whole L21 panel in LDS for n <= ~560, in chunks up to 1024.
 // nwg workgroups per matrix (1: one does everything; > 1: one factors A, the others carry B's
 // columns; `items` = device list of the nitems matrices to work on, null for all of them);
 // `scratch` holds trace_solve_blocked_scratch(n, nbatch) bytes.

@@ -2,7 +2,7 @@
 // for the unblocked reference version and the algorithmic notes).
 //
 // One workgroup (1024 threads) per batch item -- or several, see "several workgroups per matrix"
-// below -- block size NB = 16:
+// below; n <= ~560 with the whole L21 panel in LDS, up to 1024 in chunks (CHUNK) -- block size NB = 16:
 //   panel    the NB current columns of every remaining row live in REGISTERS of the row's
 //            owner thread; partial pivoting = block argmax per column, the winner publishes
 //            its row through LDS; no row is ever moved in memory (a row map keeps the pivot
