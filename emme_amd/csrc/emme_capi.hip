@@ -342,7 +342,7 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
             // never more workgroups than compute units.  Below n = 128 the hand-over costs more
             // than the idle units are worth, and beyond 8 the factoring workgroup is the limit.
             // (n = 256: four are enough, role 0 is the limit then; n = 512: two A-helpers pay)
-            nwg = std::max(1, std::min(n >= 384 ? 8 : 4, c->n_cu / n_live));
+            nwg = std::max(1, std::min(n >= 768 ? 16 : (n >= 384 ? 8 : 4), c->n_cu / n_live));
         }
         if (!fits && nwg < 2 && !c->lu_one_wg && split_env != 1) nwg = 2;
         c->last_lu_nwg = nwg;

@@ -219,12 +219,13 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 // Waits are bounded: a time-out retires the matrix with info = EMME_EDEVICE instead of hanging.
 struct SplitCtl {
     int nwg;
-    int na;            // look-ahead: workgroups that carry A's trailing columns (0: none, 1, 2)
+    int na;            // look-ahead: workgroups that carry A's trailing columns (0: none, 1 .. 5)
+    int a_cut[4];      // first column of A-helper 2, 3, .. (equal shares of the trailing work)
     int spin_limit;    // polls before a hand-over wait gives up (EMME_LU_SPIN_LIMIT; tests use 1)
     int nitems;        // matrices of this launch: role = blockIdx.x / nitems
     const int* items;  // their indices in the batch (null: 0 .. nitems-1).  A dense list, so that
                        // the workgroups spread evenly over the XCDs (block i runs on XCD i % 8)
-    int* flags;     // [nbatch][8]: panels published | helpers finished | arrivals | steps done by A-helper 1, 2
+    int* flags;     // [nbatch][8]: panels published | helpers finished | arrivals | steps done by A-helper 1 .. 5
     int* rowmaps;   // [nbatch][nblk][n]  (nwg > 1 only)
     double2* diag;  // [nbatch][n]
 };
@@ -266,11 +267,10 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     if (active && active[b] == 0) return;
     const int nwg = SPLIT ? ctl.nwg : 1, S = nwg - 1;
     // look-ahead (4 or more workgroups): role 0 applies a panel only to the NEXT panel's columns,
-    // roles 1..na to the rest of A (two of them: columns left / right of 0.65 n, equal work), so
-    // that A's trailing update leaves the factoring critical path
+    // roles 1..na to the rest of A (column ranges of equal work, cut by the host), so that A's
+    // trailing update leaves the factoring critical path
     const int na = SPLIT ? ctl.na : 0;
     const bool la = na > 0;
-    const int cA = na == 2 ? ((int)(0.65 * n) + 8) / 16 * 16 : n;  // first column of A-helper 2
     int* flag_pub = ctl.flags + 8 * b;  // the hand-over state is touched for SPLIT only
     int* snap = ctl.rowmaps + (size_t)b * ((n + NB - 1) / NB) * n;
     double2* a = A + (size_t)b * n * n;
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         // (with look-ahead, roles 1..na instead carry A's trailing columns beyond the next panel
         // and report every finished step in flags[3], flags[4]; the others share B)
         const bool a_helper = role <= na;
-        const int a_lo = role == 2 ? min(cA, n) : 0, a_hi = (na == 2 && role == 1) ? min(cA, n) : n;
+        const int a_lo = (a_helper && role > 1) ? ctl.a_cut[role - 2] : 0;
+        const int a_hi = (a_helper && role < na) ? ctl.a_cut[role - 1] : n;
         const int hB = S - na, rB = role - na - 1;  // B helpers / this one's rank
         const int f0 = a_helper ? 0 : cut16((double)rB / hB);
         const int f1 = a_helper ? 0 : (rB == hB - 1 ? n : cut16((double)(rB + 1) / hB));
@@ -507,7 +508,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         const int J0 = k0 + nbk;              // first trailing column of A
         if (SPLIT && la && k0 > 0 && J0 < n) {
             // panel j goes onto block j+1 after that block's A-helper has put panels 0 .. j-1 there
-            if (!wg_wait(flag_pub + (J0 >= cA ? 4 : 3), k0 / NB)) return;
+            int owner = 0;
+            for (int h = 0; h + 1 < na; ++h) owner += J0 >= ctl.a_cut[h];
+            if (!wg_wait(flag_pub + 3 + owner, k0 / NB)) return;
         }
         // trailing A columns (+ all of B without helpers; the next panel's only with look-ahead)
         const int Jend = SPLIT ? (la ? min(n, J0 + NB) : n) : 2 * n;
@@ -715,7 +718,22 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
     // scratch: diag | flags | row-map snapshots
     SplitCtl ctl;
     ctl.nwg = nwg;
-    ctl.na = nwg >= 6 ? 2 : (nwg >= 4 ? 1 : 0);
+    // A-helpers: about 0.4 of the helpers (A's trailing update is n^3/3, B's n^3/2), at most 5
+    // (one progress counter each); their column ranges get equal shares of the work
+    // w(x) = x^2/2 - x^3/6 of the columns left of x n
+    ctl.na = nwg >= 4 ? std::max(1, std::min(5, (int)(0.4 * (nwg - 1) + 0.5))) : 0;
+    for (int i = 0; i < 4; ++i) {
+        ctl.a_cut[i] = n;
+        if (i + 1 < ctl.na) {
+            const double target = (double)(i + 1) / (3.0 * ctl.na);
+            double lo = 0.0, hi = 1.0;
+            for (int it = 0; it < 40; ++it) {
+                const double x = 0.5 * (lo + hi);
+                (x * x / 2 - x * x * x / 6 < target ? lo : hi) = x;
+            }
+            ctl.a_cut[i] = std::min(n, ((int)(lo * n) + 8) / 16 * 16);
+        }
+    }
     {
         const char* e = std::getenv("EMME_LU_SPIN_LIMIT");
         ctl.spin_limit = e ? std::max(1, std::atoi(e)) : SPIN_LIMIT;
