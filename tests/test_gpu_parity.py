@@ -274,7 +274,8 @@ def test_trace_solve_sizes_against_lapack(emme, n):
 
 
 @pytest.mark.parametrize("n,nwg", [(256, 2), (256, 4), (200, 3), (130, 2), (37, 2), (512, 4), (16, 8),
-                                   (256, 6), (200, 7), (512, 8), (100, 5), (600, 2), (777, 5), (1024, 8)])
+                                   (256, 6), (200, 7), (512, 8), (100, 5), (600, 2), (777, 5), (1024, 8),
+                                   (512, 12), (300, 16), (900, 13)])
 def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
     """The LU with 1 + S workgroups per matrix (role 0 factors A, the others carry B's columns,
     all share the back substitution; from 4 workgroups on with look-ahead: one or two of them
@@ -305,15 +306,15 @@ def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
 
 
 def test_trace_solve_chunked_panel_is_independent_of_workgroups(emme, monkeypatch):
-    """n = 1024 (L21 panel in chunks of 512 rows): 2, 4 and 8 workgroups per matrix give the same
-    bits (with / without look-ahead, one / two A-helpers)."""
+    """n = 1024 (L21 panel in chunks of 512 rows): 2, 4, 8 and 16 workgroups per matrix give the
+    same bits (with / without look-ahead, one to five A-helpers)."""
     rng = np.random.default_rng(99)
     n, nb = 1024, 3
     A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n)) + 0.5 * n ** 0.5 * np.eye(n)
     B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
     res = []
     with _ctx(emme, example_tokamak(npoints=16)) as ctx:
-        for nwg in ("2", "4", "8"):
+        for nwg in ("2", "4", "8", "16"):
             monkeypatch.setenv("EMME_LU_SPLIT", nwg)
             res.append(ctx.trace_solve(A, B))
     for tr, info in res:
