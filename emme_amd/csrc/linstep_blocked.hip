@@ -704,15 +704,17 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
     const bool chunk = trace_solve_blocked_lds(n) > 150 * 1024;
     if (chunk && (n > BT || nwg < 2)) return hipErrorNotSupported;
     const size_t lds = chunk ? trace_solve_chunked_lds(n) : trace_solve_blocked_lds(n);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static thread_local int attr_dev = -1;  // (function attributes are per device)
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (attr_dev != cur_dev) {
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
+        attr_dev = cur_dev;
     }
     if (nwg < 1) nwg = 1;
     // scratch: diag | flags | row-map snapshots
@@ -752,12 +754,15 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         // once: workgroups the device can hold (occupancy x compute units) >= grid, else one
         // workgroup per matrix does the job.  (A cooperative launch would make the same check;
         // it is not used because its extra queue crashes rocprofv3 at process exit.)
-        static size_t cap_lds = ~(size_t)0;  // capacity of the current device for this LDS size
-        static int cap_dev = -1;
-        static long cap = 0;
+        // capacity of the current device for this build and LDS size (per host thread: contexts
+        // on different devices may be driven from different threads)
+        static thread_local size_t cap_lds = ~(size_t)0;
+        static thread_local int cap_dev = -1;
+        static thread_local long cap = 0;
+        static thread_local bool cap_chunk = false;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-        if (dev < 0 || dev != cap_dev || lds != cap_lds) {
+        if (dev < 0 || dev != cap_dev || lds != cap_lds || chunk != cap_chunk) {
             int per_cu = 0, ncu = 0;
             hipError_t eo = chunk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true, true>, BT, lds)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds);
@@ -766,7 +771,7 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
                 (void)hipGetLastError();
                 per_cu = 0;
             }
-            cap = (long)per_cu * ncu, cap_dev = dev, cap_lds = lds;
+            cap = (long)per_cu * ncu, cap_dev = dev, cap_lds = lds, cap_chunk = chunk;
         }
         if (cap >= (long)ctl.nitems * nwg) {
             if (chunk)

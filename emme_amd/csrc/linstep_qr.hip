@@ -440,11 +440,13 @@ template <int PER, int RB, int QT>
 hipError_t launch_qr(int n, int nbatch, double* Wt, const double* Mp, const int* active,
                      double* tr, int* info, hipStream_t stream) {
     const size_t lds = qr_secant_lds(n);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static thread_local int attr_dev = -1;  // (function attributes are per device)
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (attr_dev != cur_dev) {
         (void)hipFuncSetAttribute((const void*)k_qr_secant<PER, RB, QT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
+        attr_dev = cur_dev;
     }
     hipLaunchKernelGGL((k_qr_secant<PER, RB, QT>), dim3(nbatch), dim3(QT), lds, stream, n,
                        (double2*)Wt, (const double2*)Mp, active, (double2*)tr, info);
