@@ -1,29 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- omega-points solved per second on the 256-point-grid omega scan.
 
-Workload (BASELINE.json configs[2], the largest single-GPU configuration; configs[0..1]
-are parity-test cases): input-example.json with method=eigen, npoints=256,
+Workload (default, --config 3 = BASELINE.json configs[2], the largest single-GPU configuration;
+configs[0..1] are parity-test cases): input-example.json with method=eigen, npoints=256,
 omega_d_coeff=1.01 (tokamak, electrostatic, dim 256, GK15, tol 1e-6), and a lattice of
 128 initial guesses per GPU:  Re w in linspace(-1.2,-0.4,16) x Im w in linspace(0.05,0.40,8*N),
 dealt round-robin to the N ranks (weak scaling: 128 Newton chains per GPU, no data-path
-collective; one all-gather of the found roots per step, RCCL over xGMI).
+collective; ONE all-gather of the found roots per step: emme_gather_roots = ncclAllGather, RCCL
+over xGMI, through the C ABI).
 
 One "step" = one full pass of the hot path over that batch: the reference's solve-once
 sequence for every guess (2 bootstrap assemblies, then Newton steps = LU + n-RHS trace
 solve + reassembly + secant update until |dw| < 1e-6 |w|).  An omega-point = one Newton
 step (one linear solve and one assembly at a new omega); the 2 bootstrap assemblies per
-chain are overhead inside the timed region and are not counted.
+chain are overhead inside the timed region and are not counted, nor are the steps of a chain
+that ends with info != 0 (reported separately in `failed_chains`).
 
-Before the W warm-up steps the context is PREPARED once, untimed: a root search that makes it
-allocate and fill its HBM node cache (context state, like a model's weights).  The timed steps
-do the complete work of a root search each; nothing is cached between steps except that table
-of omega-independent node data, which depends on the parameter set only.
+--config 4: BASELINE configs[3] -- stellarator EM (input-stellarator-example.json + the 7 missing
+  keys), npoints=256 (dim 512, GK31), the 32x32 guess lattice around (-1.656, 2.490) dealt into
+  8 shares of 128; rank r works on share r (weak scaling); FIXED WORK: K = 8 Newton steps per guess
+  (the reference's own chain does not converge there).
+--config 5: BASELINE configs[4] -- npoints=512 tokamak ES, 32 k_rho values x 32 omega guesses dealt
+  by k_rho into 8 shares; rank r: 4 k_rho values, a fresh context (and node cache) per k_rho inside
+  the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement).
+Before the W warm-up steps the context is PREPARED once, untimed, and that cold call is REPORTED
+(`cold`): the first root search on a fresh context allocates and fills the HBM node cache.  The
+timed steps do the complete work of a root search each; nothing is cached between steps except
+that table of omega-independent node data, which depends on the parameter set only.
+
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one per GPU) when it is
+not already running under a launcher.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,11 +48,40 @@ sys.path.insert(0, ROOT)
 FLOP_PER_EVAL = 900.0       # 560 plain fp64 flops + 8 transcendentals + hypots
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector peak = fp64 MFMA peak
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md chip table
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+GOLDEN_CFG3 = os.path.join(ROOT, "tests", "golden", "cfg3_chains.npz")
+
+# The two shipped example inputs as data (values of the reference's input-example.json:1-37 and
+# input-stellarator-example.json:1-33 with the edits of SURVEY.md App. C / 8(d)).
+TOKAMAK = {
+    "conf": "tokamak", "method": "eigen", "q": 1.4, "shat": 0.78, "tau": 1.0,
+    "epsilon_n": 0.45, "epsilon_r": 0.0, "eta_i": 3.13, "eta_e": 3.13, "k_rho": 0.3182,
+    "beta_e": 0.0, "R": 1.0, "vt": 1.0, "omega_d_coeff": 1.01, "length": 20.0, "theta": 0.0,
+    "npoints": 256, "iteration_step_limit": 20, "initial_guess": [-0.8, 0.25],
+    "integration_precision": 1.0e-6, "integration_accuracy": 1.0e-6,
+    "integration_iteration_limit": 100, "integration_start_points": 15, "arc_coeff": 100.0,
+    "iteration_precision": 1.0e-6, "iteration_method": "TraceSecant",
+    "water_bag_weight_vpara": 1.0, "water_bag_weight_vperp": 1.0,
+    "drift_center_transformation_switch": True,
+}
+STELLARATOR = {
+    "conf": "stellarator", "q": 2.0, "shat": -1.0, "tau": 1.0, "epsilon_n": 0.3,
+    "eta_i": 3.0, "eta_e": 3.0, "k_rho": 0.247487, "beta_e": 0.02, "R": 1.0, "vt": 1.0,
+    "length": 10.0, "theta": 0.0, "npoints": 256, "iteration_step_limit": 100,
+    "integration_precision": 1.0e-5, "integration_accuracy": 1.0e-2,
+    "integration_iteration_limit": 20, "integration_start_points": 31, "arc_coeff": 100.0,
+    "eta_k": 0.0, "lh": 2, "mh": 10, "epsilon_h_t": 1.0, "alpha_0": 0.0, "r_over_R": 0.1,
+    "initial_guess": [-1.656, 2.490], "iteration_precision": 1.0e-6,
+    "method": "eigen", "iteration_method": "TraceSecant", "epsilon_r": 0.0,
+    "omega_d_coeff": 1.0, "water_bag_weight_vpara": 1.0, "water_bag_weight_vperp": 1.0,
+    "drift_center_transformation_switch": True,
+}
 
 
-def workload_dict(npoints):
-    from oracle.binding import example_tokamak  # plain data (the example input's values)
-    return example_tokamak(npoints=npoints, omega_d_coeff=1.01)
+def workload_dict(npoints=256, **over):
+    d = dict(TOKAMAK, npoints=npoints, omega_d_coeff=1.01)
+    d.update(over)
+    return d
 
 
 def lattice(world, rank, per_gpu=128):
@@ -47,6 +89,19 @@ def lattice(world, rank, per_gpu=128):
     im = np.linspace(0.05, 0.40, (per_gpu // 16) * world)
     g = (re[None, :] + 1j * im[:, None]).reshape(-1)
     return g[rank::world].copy()
+
+
+def lattice_cfg4(share):
+    """32 x 32 guesses around the stellarator example's initial guess, dealt into 8 shares."""
+    re, im = np.linspace(-1.756, -1.556, 32), np.linspace(2.39, 2.59, 32)
+    return (re[None, :] + 1j * im[:, None]).reshape(-1)[share % 8::8].copy()
+
+
+def sweep_cfg5(share):
+    """(k_rho values of this share, the 32 omega guesses every k_rho starts from)."""
+    krs = np.linspace(0.2, 0.5, 32)[share % 8::8]
+    g = (np.linspace(-1.0, -0.5, 8)[None, :] + 1j * np.linspace(0.1, 0.4, 4)[:, None]).reshape(-1)
+    return krs, g
 
 
 def usable_cores():
@@ -61,94 +116,148 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(d, guesses, budget_s=25.0):
-    """Reference CPU path on this box's host cores, bounded sample of the same workload.
-
-    kind "reference": the reference's own kappa/quadrature sources (oracle/_ref, built from
-    /root/reference in the build container) fill the matrix on all host cores, and the
-    Newton linear step is the same LAPACK routine the reference calls (zsysv, SciPy's
-    OpenBLAS).  Falls back to the C restatement (kind "port") when _ref did not travel.
-    """
+def cpu_root_searches(d, guesses, kind, budget_s):
+    """The reference's solve-once sequence on the host cores, chain after chain, until the budget is
+    spent.  kind "reference": oracle/_ref (the reference's own kappa/quadrature sources) fills the
+    matrix; kind "port": the C restatement oracle/emme_oracle.c with the reference's per-call
+    re-evaluation of g()/bi() switched on.  Newton linear step: LAPACK zsysv (SciPy's OpenBLAS), the
+    routine the reference calls (include/solver.h:134-136).  Phases mirror the reference's Timer rows
+    (src/main.cpp:25-76): initial, Iteration (of which integration, linear solver)."""
     from oracle.binding import Oracle, Reference
     cores = usable_cores()
-    n = d["npoints"]
-    tol = d["iteration_precision"]
-    limit = d["iteration_step_limit"]
-    use_ref = Reference.available()
-    if use_ref:
+    n, tol, limit = d["npoints"], d["iteration_precision"], d["iteration_step_limit"]
+    if kind == "reference":
         ref = Reference()
         ref.open_dict(d)
         assemble = lambda w: ref.assemble(n, w, cores)
-        kind = "reference"
     else:
         orc = Oracle()
         po = orc.params(d)
         assemble = lambda w: orc.assemble(po, w, cores, recompute=1)[0]
-        kind = "port"
-    try:
-        from scipy.linalg.lapack import zsysv
-
-        def trace_step(M, Mp):
-            # include/solver.h:134-139: zsysv("Upper", n, n, M, ..., M', ...) ; -1/trace
-            _, _, x, info = zsysv(M, Mp, lower=0)
-            return np.trace(x), info
-    except Exception:  # pragma: no cover
-        def trace_step(M, Mp):
-            return np.trace(np.linalg.solve(M, Mp)), 0
-
+    from scipy.linalg.lapack import zsysv
+    ph = {"initial": 0.0, "Iteration": 0.0, "integration": 0.0, "linear solver": 0.0}
     t0 = time.perf_counter()
-    points = 0
-    roots = 0
+    points, chains = 0, []
     for g in guesses:
+        ta = time.perf_counter()
         w = 0.99 * g
         dw = 0.01 * g
         Mold = assemble(complex(w))
         w = w + dw
         M = assemble(complex(w))
         Mp = (M - Mold) / dw
+        tb = time.perf_counter()
+        ph["initial"] += tb - ta
+        k, ok = 0, False
         for _ in range(limit + 1):
             Mold = M
-            tr, info = trace_step(M.copy(), Mp)
-            dw = -1.0 / tr
+            t1 = time.perf_counter()
+            _, _, x, info = zsysv(M.copy(), Mp, lower=0)  # include/solver.h:134-139
+            dw = -1.0 / np.trace(x)
+            t2 = time.perf_counter()
             w = w + dw
             M = assemble(complex(w))
             Mp = (M - Mold) / dw
-            points += 1
+            t3 = time.perf_counter()
+            ph["linear solver"] += t2 - t1
+            ph["integration"] += t3 - t2
+            k += 1
             if abs(dw) < abs(tol * w):
+                ok = True
                 break
-        roots += 1
+        ph["Iteration"] += time.perf_counter() - tb
+        points += k
+        chains.append((complex(g), complex(w), k, ok))
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     return {"value": points / dt, "unit": "omega-points/s", "cores": cores, "kind": kind,
-            "sample": f"{roots} of the lattice guesses (every 16th from #7), full root search each: "
+            "sample": f"{len(chains)} of the lattice guesses (every 16th from #7), full root search each: "
                       f"{points} omega-points in {dt:.1f} s",
-            "roots_per_s": roots / dt}
+            "roots_per_s": len(chains) / dt,
+            "phases_s": {k: round(v, 3) for k, v in ph.items()}}, chains
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this build
-    (profiles/, separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md); bench.py cannot
-    collect hardware counters itself.  Raw counter figures (no gfx950 x2 read correction)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v9_pmc_summary.json")
+def cpu_baseline(d, guesses, gpu_roots, gpu_iters, sample_idx):
+    """cpu_baseline object of the bench line + the parity of the GPU roots against the CPU roots of
+    the same guesses (the CPU leg is the checker here, never the thing measured as `value`)."""
+    from oracle.binding import Reference
+    out, chains = None, []
+    if Reference.available():
+        out, chains = cpu_root_searches(d, guesses, "reference", 18.0)
+        port, _ = cpu_root_searches(d, guesses, "port", 8.0)
+        out["port"] = {k: port[k] for k in ("value", "sample", "phases_s")}
+        out["note"] = ("kind=reference: oracle/_ref/libemme_ref.so, the reference's own kappa sources built in the "
+                       "build container, travelled to this box as a built file; `port` = the C restatement timed "
+                       "beside it (it is not a strawman: same algorithm, same per-call g()/bi() re-evaluation)")
+    else:
+        out, chains = cpu_root_searches(d, guesses, "port", 25.0)
+    err, rel, n_cmp, it_mismatch = 0.0, 0.0, 0, 0
+    for (g, w, k, ok), b in zip(chains, sample_idx):
+        if not ok:
+            continue  # a chain the reference itself does not converge has no root to compare
+        e = abs(gpu_roots[b] - w)
+        err, rel = max(err, e), max(rel, e / abs(w))
+        it_mismatch += int(gpu_iters[b] != k)
+        n_cmp += 1
+    return out, {"chains_compared": n_cmp, "max_abs_err": err, "max_rel_err": rel,
+                 "iteration_count_mismatches": it_mismatch}
+
+
+def golden_parity(roots, iters, info):
+    """GPU roots of the 128-guess lattice against tests/golden/cfg3_chains.npz (all 128 chains computed
+    in the build container with the reference's kappa sources + LAPACK zsysv)."""
+    if not os.path.exists(GOLDEN_CFG3):
+        return None
+    z = np.load(GOLDEN_CFG3)
+    done = z["done"].astype(bool) if "done" in z else np.ones(len(z["roots"]), bool)
+    conv = done & (z["converged"] == 1)
+    gpu_conv = (info == 0)
+    both = conv & gpu_conv & (iters <= z["iterates"].shape[1])
+    e = np.abs(roots[both] - z["roots"][both])
+    rel = e / np.abs(z["roots"][both])
+    return {"chains_in_fixture": int(done.sum()), "reference_converged": int(conv.sum()),
+            "compared": int(both.sum()), "max_abs_err": float(e.max()) if e.size else None,
+            "max_rel_err": float(rel.max()) if rel.size else None,
+            "iteration_count_mismatches": int((iters[both] != z["iters"][both]).sum())}
+
+
+def pmc_summary(kernel):
+    """Executed-work figures of `kernel` from the committed rocprofv3 --pmc summary of this build
+    (profiles/, separate passes, see profiles/README.md); bench.py cannot collect hardware counters
+    itself.  Returns the kernel's dict or None."""
     try:
-        k = json.load(open(path))["kernels"][kernel]
-        return (k["hbm_fetch_bytes_per_launch"] + k["hbm_write_bytes_per_launch"],
-                "FETCH_SIZE + WRITE_SIZE per launch, raw, from profiles/r01_v9_pmc_summary.json "
-                "(rocprofv3 --pmc passes over tools/iter_profile.py, same workload)")
+        return json.load(open(PMC_SUMMARY))["kernels"][kernel]
     except (OSError, KeyError, ValueError):
-        return None, "no PMC summary for this kernel under profiles/"
+        return None
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--npoints", type=int, default=256)
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5])
+    ap.add_argument("--npoints", type=int, default=None)
     ap.add_argument("--per-gpu", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-cold", action="store_true", help="skip the no-cache / cold-start side measurements")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start the N ranks ourselves, BEFORE anything touches the GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -156,9 +265,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
     if use_dist:
@@ -168,14 +276,18 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import emme_amd
-    from emme_amd.scan import gather_roots
+    from emme_amd.scan import ScanGather, gather_roots
 
-    d = workload_dict(args.npoints)
-    params = emme_amd.params_from_dict(d)
-    guesses = lattice(world, rank, args.per_gpu)
-    ctx = emme_amd.Context(params, device=local_rank)
     stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
+    gather_kind = "none (1 rank)"
+    sg = None
+    if use_dist:
+        try:
+            sg = ScanGather(rank, world, device=local_rank)
+            gather_kind = "emme_gather_roots (C ABI, ncclAllGather / RCCL)"
+        except Exception as e:  # never lose the scaling run over the 4 KiB gather
+            print(f"warning: RCCL gather through the C ABI unavailable ({e}); using torch.distributed", file=sys.stderr)
+            gather_kind = "torch.distributed all_gather_into_tensor (RCCL)"
 
     def barrier():
         torch.cuda.synchronize()
@@ -183,55 +295,129 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        roots, iters, info = ctx.solve_roots(guesses)
-        allroots = gather_roots(roots, iters, info, world, force_dist=use_dist)  # ONE all-gather (RCCL)
-        return roots, iters, info, allroots
+    def gather(roots, iters, info, n_total):
+        if sg is not None:
+            return sg.gather(roots, iters, info, n_total, stream.cuda_stream)
+        return gather_roots(roots, iters, info, world, n_total, force_dist=use_dist)
 
-    # Context preparation, outside warm-up and timing (the analogue of building a model and
-    # initialising its weights): one untimed root search makes the context allocate and fill its
-    # HBM node cache (2-3 s, almost all of it hipMalloc of ~150 GB) and grow it where this
-    # workload's integrals go deep.  Every timed step still does the full work of a root search.
-    ctx.solve_roots(guesses)
+    cfg = args.config
+    cold = {}
+    if cfg == 3:
+        npoints = args.npoints or 256
+        d = workload_dict(npoints)
+        guesses = lattice(world, rank, args.per_gpu)
+        n_total = args.per_gpu * world
+        solve_kw = {}
+        what = (f"input-example.json (tokamak ES, method=eigen, omega_d_coeff=1.01), npoints={npoints}, "
+                f"{args.per_gpu}-guess omega lattice per GPU (Re -1.2..-0.4 x Im 0.05..0.40), full TraceSecant "
+                f"root search per guess")
+    elif cfg == 4:
+        npoints = args.npoints or 256
+        d = dict(STELLARATOR, npoints=npoints)
+        guesses = lattice_cfg4(rank)
+        n_total = len(guesses) * world
+        solve_kw = {"step_limit": 7, "tol": 0.0}
+        what = (f"input-stellarator-example.json + the 7 missing keys (stellarator EM, beta_e=0.02, GK31), "
+                f"npoints={npoints} (dim {2 * npoints}), 32x32 guess lattice around (-1.656, 2.490) in 8 shares "
+                f"of 128, share r on rank r, FIXED WORK K=8 TraceSecant Newton steps per guess")
+    else:
+        npoints = args.npoints or 512
+        krs, guesses = sweep_cfg5(rank)
+        d = workload_dict(npoints, k_rho=float(krs[0]))
+        n_total = len(krs) * len(guesses) * world
+        solve_kw = {}
+        what = (f"input-example.json (tokamak ES), npoints={npoints}, (k_rho, omega) sweep: 32 k_rho in 0.2..0.5 x "
+                f"32 guesses dealt by k_rho into 8 shares, share r on rank r ({len(krs)} k_rho values, a FRESH "
+                f"context + node cache per k_rho inside the timed region), full root search per guess")
+
+    # ---- context preparation (cfg 3/4), outside warm-up and timing but REPORTED: the first root search
+    # on a fresh context allocates and fills its HBM node cache and grows it where this workload's
+    # integrals go deep.  Every timed step still does the full work of a root search.
+    ctx = None
+    if cfg in (3, 4):
+        params = emme_amd.params_from_dict(d)
+        t0 = time.perf_counter()
+        ctx = emme_amd.Context(params, device=local_rank)
+        ctx.set_stream(stream.cuda_stream)
+        ctx.profile(True)
+        r0, i0, f0 = ctx.solve_roots(guesses, **solve_kw)
+        torch.cuda.synchronize()
+        first_s = time.perf_counter() - t0
+        pr0 = ctx.profile_read(reset=True)
+        ok0 = f0 == 0
+        cold = {"first_call_s": first_s,
+                "first_call_omega_points_per_s": float(i0[ok0].sum()) / first_s,
+                "node_cache_build_ms": pr0.cache_build_ms, "node_cache_build_launches": pr0.cache_build_launches,
+                "node_cache_alloc_ms": pr0.cache_alloc_ms,
+                "node_cache_gib_after_first_call": ctx.node_cache_gib(),
+                "note": "first solve_roots on a FRESH context of this process (context creation, hipMalloc of the "
+                        "node cache, its build kernels and cache growth included); the timed steps below run on "
+                        "the prepared context"}
+
+    def step():
+        if cfg == 5:
+            rs, its, infs = [], [], []
+            for kr in krs:
+                with emme_amd.Context(emme_amd.params_from_dict(workload_dict(npoints, k_rho=float(kr))),
+                                      device=local_rank) as c5:
+                    c5.set_stream(stream.cuda_stream)
+                    r, i, f = c5.solve_roots(guesses)
+                rs.append(r), its.append(i), infs.append(f)
+            roots, iters, info = np.concatenate(rs), np.concatenate(its), np.concatenate(infs)
+        else:
+            roots, iters, info = ctx.solve_roots(guesses, **solve_kw)
+        allr = gather(roots, iters, info, n_total) if use_dist else (roots, iters, info)
+        return roots, iters, info, allr
+
     for _ in range(args.warmup):
         step()
-    ctx.profile(True)
-    ctx.profile_read(reset=True)
+    if ctx is not None:
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     points = 0
     for _ in range(args.steps):
         roots, iters, info, allroots = step()
-        points += int(iters.sum())
+        points += int(iters[info == 0].sum())
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
+    prof = ctx.profile_read() if ctx is not None else None
 
-    stats = torch.tensor([dt, float(points), float((info == 0).sum()), float(len(guesses))],
-                         dtype=torch.float64, device="cuda")
+    stats = torch.tensor([dt, float(points), float((info == 0).sum()), float(len(roots)),
+                          float(iters[info != 0].sum())], dtype=torch.float64, device="cuda")
+    tmean = dt
     if use_dist:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        tmean = float(stats[0]) / world
         dt = float(tmax[0])
     total_points = float(stats[1])
+
+    # ---- side measurement (rank 0, cfg 3): the same search without the node cache (a one-shot caller)
+    if rank == 0 and cfg == 3 and not args.no_cold and world == 1:
+        old = os.environ.get("EMME_NODE_CACHE_GB")
+        os.environ["EMME_NODE_CACHE_GB"] = "0"
+        try:
+            with emme_amd.Context(emme_amd.params_from_dict(d), device=local_rank) as c0:
+                c0.set_stream(stream.cuda_stream)
+                c0.solve_roots(guesses)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rn, inn, fn = c0.solve_roots(guesses)
+                torch.cuda.synchronize()
+                tn = time.perf_counter() - t1
+                cold["no_cache_omega_points_per_s"] = float(inn[fn == 0].sum()) / tn
+                cold["no_cache_ms_per_step"] = tn * 1e3
+                cold["no_cache_fill_kernel"] = c0.fill_kernel()
+        finally:
+            if old is None:
+                os.environ.pop("EMME_NODE_CACHE_GB", None)
+            else:
+                os.environ["EMME_NODE_CACHE_GB"] = old
+
     if rank == 0:
-        evals = prof.integrand_evals
-        fill_s = (prof.assemble_ms + prof.deferred_ms) * 1e-3
-        asm_s = prof.assemble_ms * 1e-3
-        n_launch = max(prof.assemble_launches, 1)
-        # algorithmic work per launch = integrand evaluations the reference algorithm performs
-        # for these matrices (counted exactly by the kernels: GK intervals x 15 nodes) x the
-        # SURVEY 8(d) figure of 900 flop-equivalents per evaluation, over ALL fill kernels
-        flop_per_launch = evals * FLOP_PER_EVAL / n_launch
-        avg_launch_s = fill_s / n_launch
-        achieved_tf = flop_per_launch / avg_launch_s / 1e12 if fill_s > 0 else 0.0
-        dim = ctx.dim
-        # bytes the fill must move: node records consumed (15 x 64 B per interval evaluated by
-        # the cached kernel; they stream from HBM / Infinity Cache / L2) + dim^2 entries written
-        # (16 B M, 16 B M', 16 B read of M_old in the fused secant epilogue)
-        bytes_alg = prof.gk_intervals * 15 * 64.0 + prof.matrices * dim * dim * 48.0
-        traffic, traffic_note = pmc_traffic("k_assemble_union<15, 2>")
         out = {
             "metric": "omega-points solved/sec (256-pt grid)",
             "value": total_points / dt,
@@ -245,61 +431,109 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"input-example.json (tokamak ES, method=eigen, omega_d_coeff=1.01), "
-                                   f"npoints={args.npoints}, {args.per_gpu}-guess omega lattice per GPU "
-                                   f"(Re -1.2..-0.4 x Im 0.05..0.40), full TraceSecant root search per guess",
-                       "grid_points": args.npoints, "guesses_per_gpu": args.per_gpu,
-                       "parallelism": f"scan-shard x{world}"},
+            "config": {"workload": what, "baseline_config": cfg - 1, "grid_points": npoints,
+                       "chains_per_gpu": int(len(roots)), "parallelism": f"scan-shard x{world}",
+                       "gather": gather_kind},
             "roots_per_s": float(stats[3]) * args.steps / dt,
             "omega_points_per_step": total_points / args.steps,
-            "converged_fraction": float(stats[2]) / float(stats[3]),
-            "roofline": {
-                "bound": "fp64-valu",  # neither HBM nor MFMA bounds this path
-                "kernel": ctx.fill_kernel() + " (+ k_assemble_coop for deferred integrals)",
-                "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_VECTOR_PEAK_TF,
-                "traffic": traffic, "traffic_note": traffic_note,
-                "avg_launch_ms": avg_launch_s * 1e3, "launches": prof.assemble_launches,
-                "integrand_evals_per_launch": evals / n_launch,
-                "flop_per_eval_convention": FLOP_PER_EVAL,
-                "note": "ALGORITHMIC flop-equivalents of the reference algorithm (SURVEY 8d: 900 per "
-                        "integrand evaluation) per second. The kernels do far fewer real flops per "
-                        "evaluation: the omega-independent part of the integrand (Bessel recurrence, "
-                        "sincos, rsqrt) is computed once per context and read back from the HBM node "
-                        "cache, so frac can exceed 1; executed-instruction utilisation and memory "
-                        "counters are in profiles/ and DESIGN.md",
-            },
-            "roofline_hbm": {
-                "bound": "hbm", "kernel": ctx.fill_kernel(),
-                "achieved": bytes_alg / asm_s / 1e9 if asm_s > 0 else 0.0,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (bytes_alg / asm_s / 1e9) / HBM_PEAK_GBS if asm_s > 0 else 0.0,
-                "algorithmic_bytes_per_launch": bytes_alg / n_launch,
-                "traffic": traffic, "traffic_note": traffic_note,
-                # what actually crossed the HBM interface (PMC) over the measured launch time
-                "hbm_measured_GBps": (traffic / (asm_s / n_launch) / 1e9) if (traffic and asm_s > 0) else None,
-                "note": "algorithmic bytes = node records consumed + matrix entries written, per second "
-                        "of the main fill kernel. About 80 % of the record reads are served by L1 / L2 / "
-                        "Infinity Cache (the omegas of a chunk read the same records), so this figure can "
-                        "exceed the HBM peak; `traffic` / `hbm_measured_GBps` are the bytes that really "
-                        "crossed the HBM interface (raw FETCH_SIZE + WRITE_SIZE, no x2 correction)",
-            },
-            "node_cache_gib": ctx.node_cache_gib(),
-            "kernels_ms_per_step": {
+            "chains_info0_fraction": float(stats[2]) / float(stats[3]),
+            "omega_points_of_failed_chains_per_step_not_counted": float(stats[4]),
+            "rank_time_max_over_mean": dt / tmean if tmean > 0 else None,
+            "cold": cold,
+        }
+        bad = np.nonzero(info != 0)[0]
+        out["failed_chains"] = [{"index": int(b), "guess": [guesses[b % len(guesses)].real, guesses[b % len(guesses)].imag],
+                                 "info": int(info[b]), "steps": int(iters[b]), "last_omega": [roots[b].real, roots[b].imag]}
+                                for b in bad[:8]]
+        if prof is not None:
+            evals = prof.integrand_evals
+            fill_s = (prof.assemble_ms + prof.deferred_ms) * 1e-3
+            asm_s = prof.assemble_ms * 1e-3
+            n_launch = max(prof.assemble_launches, 1)
+            avg_launch_s = asm_s / n_launch
+            kname = ctx.fill_kernel_symbol()
+            pm = pmc_summary(kname)
+            # algorithmic convention of SURVEY 8(d): integrand evaluations the REFERENCE algorithm performs
+            # for these matrices (counted exactly by the kernels: GK intervals x nodes) x 900 flop-eq
+            alg_tf = evals * FLOP_PER_EVAL / fill_s / 1e12 if fill_s > 0 else 0.0
+            roof = {"bound": "fp64-valu", "kernel": kname,
+                    "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                    "avg_launch_ms": avg_launch_s * 1e3, "launches": prof.assemble_launches,
+                    "algorithmic_speedup_vs_fp64_peak": alg_tf / FP64_VECTOR_PEAK_TF,
+                    "algorithmic_TFLOPeq_per_s": alg_tf, "flop_per_eval_convention": FLOP_PER_EVAL,
+                    "integrand_evals_per_launch": evals / n_launch}
+            if pm and "fp64_flop_issued_per_launch" in pm:
+                ach = pm["fp64_flop_issued_per_launch"] / avg_launch_s / 1e12
+                roof.update({
+                    "achieved": ach, "frac": ach / FP64_VECTOR_PEAK_TF,
+                    "frac_useful_lanes": ach * pm.get("lane_utilisation", 1.0) / FP64_VECTOR_PEAK_TF,
+                    "lane_utilisation": pm.get("lane_utilisation"),
+                    "fp64_share_of_valu_instructions": pm.get("fp64_share_of_valu"),
+                    "fp64_flop_issued_per_launch": pm["fp64_flop_issued_per_launch"],
+                    "traffic": pm.get("hbm_fetch_bytes_per_launch", 0.0) + pm.get("hbm_write_bytes_per_launch", 0.0),
+                    "traffic_corrected": 2.0 * pm.get("hbm_fetch_bytes_per_launch", 0.0) + pm.get("hbm_write_bytes_per_launch", 0.0),
+                    "note": "EXECUTED work: FP64 operations issued by the dominant fill kernel per launch (rocprofv3 "
+                            "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2 flop, + MFMA F64 ops; "
+                            f"{os.path.relpath(PMC_SUMMARY, ROOT)}, same workload) / hipEvent launch duration measured "
+                            "in THIS run / fp64 vector peak.  frac_useful_lanes = x lane utilisation.  `traffic` = raw "
+                            "FETCH_SIZE + WRITE_SIZE per launch, traffic_corrected with the gfx950 x2 read correction. "
+                            "algorithmic_speedup_vs_fp64_peak is the SURVEY 8(d) convention (900 flop-eq per "
+                            "integrand evaluation of the REFERENCE algorithm): a speed-up over a peak-rate "
+                            "reference-style kernel, not a utilisation"})
+            else:
+                roof.update({"achieved": None, "frac": None, "traffic": None,
+                             "note": f"no PMC summary for {kname} under profiles/ (executed-work roofline unavailable)"})
+            out["roofline"] = roof
+            dim = ctx.dim
+            nodes = 15 if d["integration_start_points"] == 15 else 31
+            out["assembly_hbm"] = {
+                "matrix_bytes_written_GBps": prof.matrices * dim * dim * 32.0 / fill_s / 1e9 if fill_s > 0 else 0.0,
+                "peak": HBM_PEAK_GBS,
+                "measured_GBps": (roof.get("traffic") / avg_launch_s / 1e9) if roof.get("traffic") else None,
+                "note": "north_star's 'assembly HBM GB/s': M and M' written (32 B per entry); the fill is FP64-ALU "
+                        "bound (SURVEY 0.4), so this is << 8 TB/s by construction; measured = PMC traffic / launch time"}
+            out["node_cache_gib"] = ctx.node_cache_gib()
+            out["kernels_ms_per_step"] = {
                 "fill_main": prof.assemble_ms / args.steps,
                 "fill_deferred": prof.deferred_ms / args.steps,
                 "linstep_lu_trace": prof.linstep_ms / args.steps,
                 "other": prof.other_ms / args.steps,
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(d, guesses[7::16])
+                "host_gaps_and_copies": dt / args.steps * 1e3 - (prof.assemble_ms + prof.deferred_ms + prof.linstep_ms
+                                                                  + prof.other_ms) / args.steps,
+            }
+            _ = nodes
+        if cfg == 3 and world == 1 and args.per_gpu == 128 and npoints == 256:
+            gp = golden_parity(roots, iters, info)
+            if gp is not None:
+                out["parity_golden"] = gp
+        if not args.no_cpu_baseline and world == 1 and cfg == 3:
+            sample = list(range(7, len(guesses), 16))
+            out["cpu_baseline"], par = cpu_baseline(d, guesses[7::16], roots, iters, sample)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    ctx.close()
+            out["parity_sample_max_abs_err"] = par["max_abs_err"]
+            out["parity_sample"] = par
+        print(json.dumps(out), flush=True)
+        # the bench checks itself: GPU roots must be the reference's (1e-9 relative)
+        fail = []
+        if out.get("parity_sample", {}).get("chains_compared", 0) and out["parity_sample"]["max_rel_err"] > 1e-9:
+            fail.append(f"live CPU sample: max rel err {out['parity_sample']['max_rel_err']:.3e}")
+        if out.get("parity_golden") and out["parity_golden"]["compared"] and out["parity_golden"]["max_rel_err"] > 1e-9:
+            fail.append(f"golden chains: max rel err {out['parity_golden']['max_rel_err']:.3e}")
+        if fail:
+            print("PARITY FAILURE: " + "; ".join(fail), file=sys.stderr)
+            rc = 3
+        else:
+            rc = 0
+    else:
+        rc = 0
+    if ctx is not None:
+        ctx.close()
+    if sg is not None:
+        sg.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

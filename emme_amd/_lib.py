@@ -65,6 +65,10 @@ class Profile(C.Structure):
         ("other_ms", C.c_double), ("other_launches", C.c_long),
         ("gk_intervals", C.c_longlong), ("integrand_evals", C.c_longlong),
         ("matrices", C.c_longlong), ("union_rounds", C.c_longlong),
+        ("cache_build_ms", C.c_double), ("cache_build_launches", C.c_long),
+        ("cache_alloc_ms", C.c_double),
+        ("dense_rounds", C.c_longlong), ("sparse_rounds", C.c_longlong),
+        ("sparse_columns", C.c_longlong), ("tile_tasks", C.c_longlong),
     ]
 
 
@@ -86,6 +90,7 @@ def load():
     lib.emme_tables.argtypes = [PP, P, P, P, P]
     lib.emme_weight.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.emme_weight.restype = C.c_double
+    lib.emme_bessel_batch.argtypes = [P, C.c_int, P]
     lib.emme_ctx_create.argtypes = [PP, C.c_int, C.POINTER(P)]
     lib.emme_ctx_destroy.argtypes = [P]
     lib.emme_ctx_destroy.restype = None
@@ -109,6 +114,11 @@ def load():
     lib.emme_free.argtypes = [C.c_void_p]
     lib.emme_free.restype = None
     lib.emme_scan_values.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, P, P, C.c_int]
+    lib.emme_comm_unique_id.argtypes = [P]
+    lib.emme_comm_create.argtypes = [P, C.c_int, C.c_int, C.c_int, C.POINTER(P)]
+    lib.emme_comm_destroy.argtypes = [P]
+    lib.emme_comm_destroy.restype = None
+    lib.emme_gather_roots.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P, P, P]
     _LIB = lib
     return lib
 
@@ -172,6 +182,14 @@ def weight(n, i, j) -> float:
     return load().emme_weight(n, i, j)
 
 
+def bessel(z) -> np.ndarray:
+    """util::bessel_i_alter_helper (include/functions.h:381-408) on the device: [n, 4] complex."""
+    z = np.ascontiguousarray(np.atleast_1d(z), dtype=np.complex128)
+    out = np.zeros((len(z), 4), dtype=np.complex128)
+    _check(load().emme_bessel_batch(z.ctypes.data, len(z), out.ctypes.data))
+    return out
+
+
 def null_vector(M) -> np.ndarray:
     """nullSpace (reference include/solver.h:58-112) of a complex symmetric matrix."""
     M = np.ascontiguousarray(M, dtype=np.complex128)
@@ -207,6 +225,53 @@ def run_json(text: str, matrix_dir: str | None = None) -> dict:
 def release_pooled_memory() -> None:
     """Give the node-cache buffers kept from destroyed contexts back to the driver."""
     load().emme_release_pooled_memory()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI (rank 0 calls it and hands the bytes to the others)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().emme_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the scan's one collective (emme_comm_* in include/emme_hip.h)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = -1):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.lib = load()
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        _check(self.lib.emme_comm_create(unique_id, rank, world, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.emme_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gather_roots(self, roots, iters, info, n_total: int, stream_handle: int = 0):
+        """ONE ncclAllGather of {w_re, w_im, iters, info}; returns all n_total results in item
+        order (item k was solved by rank k mod world) on every rank."""
+        r = np.ascontiguousarray(roots, dtype=np.complex128)
+        it = np.ascontiguousarray(iters, dtype=np.int32)
+        inf = np.ascontiguousarray(info, dtype=np.int32)
+        ra = np.zeros(n_total, dtype=np.complex128)
+        ia = np.zeros(n_total, dtype=np.int32)
+        fa = np.zeros(n_total, dtype=np.int32)
+        _check(self.lib.emme_gather_roots(self.h, C.c_void_p(stream_handle), r.ctypes.data, it.ctypes.data,
+                                          inf.ctypes.data, len(r), n_total, ra.ctypes.data, ia.ctypes.data,
+                                          fa.ctypes.data))
+        return ra, ia, fa
 
 
 def _c128(a, shape=None):
@@ -247,10 +312,27 @@ class Context:
 
     FILL_KERNELS = {0: "k_assemble (lanes=nodes)", 1: "k_assemble_wl (omega-lane)",
                     2: "k_assemble_cached (HBM node cache)",
-                    3: "k_assemble_union (HBM node cache + phase table)"}
+                    3: "k_assemble_union (HBM node cache + phase table)",
+                    4: "k_assemble_dense (tiled HBM node cache, FP64 matrix cores)"}
 
     def fill_kernel(self) -> str:
         return self.FILL_KERNELS.get(self.lib.emme_ctx_fill_mode(self.h), "none yet")
+
+    def fill_kernel_symbol(self) -> str:
+        """Name of the last fill's main kernel as rocprofv3 prints it (key of profiles/*_pmc_summary.json)."""
+        mode = self.lib.emme_ctx_fill_mode(self.h)
+        pts = self.params.integration_start_points
+        em = self.params.beta_e != 0.0
+        folded = "false" if os.environ.get("EMME_PHASE_TABLE") == "0" else "true"
+        if mode == 4:
+            return "k_assemble_dense"
+        if mode == 3:
+            return "k_assemble_union<15, %d>" % int(os.environ.get("EMME_UNION_SEL", "2"))
+        if mode == 2:
+            return f"k_assemble_cached_em<{pts}, {folded}>" if em else f"k_assemble_cached<{pts}, {folded}>"
+        if mode == 1:
+            return f"k_assemble_wl<{pts}>"
+        return f"k_assemble<{pts}, false>"
 
     def node_cache_gib(self) -> float:
         return self.lib.emme_ctx_node_cache_gib(self.h)

@@ -49,6 +49,7 @@ struct AsmArgs {
     // moment m multiplies them by (c_nv W)^m with W from wtab (null = one record per moment)
     const double2* wtab[2];
     int folded;  // cached records are in the folded form (exp(A0) inside the amplitudes)
+    int tiled;   // the cache is in the tiled layout of the dense fill (node_cache.hpp): `recs` point to doubles
     unsigned int count_lo, count_hi;  // k_assemble_coop: run only if count_lo <= list length < count_hi
 };
 
@@ -67,6 +68,28 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
     const int cslot = A.recs[cls] ? A.geom.slot(depth, path, which) : -1;
     const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? A.recs[cls] : A.recs_ext[cls][which]);
     NodeData d;
+    if (buf && A.tiled) {
+        // tiled layout (electrostatic GK15, folded): block of the pair's tile, node slot of this lane
+        const double* tb = reinterpret_cast<const double*>(buf);
+        const long tile = cache_item / TILE_PAIRS;
+        const int p = (int)(cache_item - tile * TILE_PAIRS);
+        const double* blk =
+            which < 0 ? tb + ((size_t)tile * A.geom.ni_main() + cslot) * TILE_BLOCK
+                      : tb + ((size_t)tile * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * TILE_BLOCK;
+        const int sn = slotnode_of_lane(lane_in_group);
+        const cd q1 = mk(blk[(2 * sn) * 16 + p], blk[512 + (2 * sn) * 16 + p]);
+        const cd q0 = mk(blk[(2 * sn + 1) * 16 + p], blk[512 + (2 * sn + 1) * 16 + p]);
+        const double rea0 = blk[1024 + lane_in_group * 16 + p];
+        const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
+        const cd arg = mk(tt.x, tt.y) * oc.omega;
+        if (!(rea0 + arg.x >= -40.)) {
+            if (rea0 + arg.x < -40.) return mk(0.0, 0.0);  // safe_exp clamp, src/Parameters.cpp:167-173
+        }
+        double sa, ca;
+        fsincos(arg.y, sa, ca, tc);
+        const double ea = fexp(arg.x, tc);
+        return mk(ea * ca, ea * sa) * (oc.omega * q1 + q0);
+    }
     if (buf) {
         const bool shared = A.wtab[cls] != nullptr;
         const long ci = shared ? cache_item / A.P.nm : cache_item;
@@ -111,7 +134,7 @@ template <int PTS, bool LIST>
 __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
-    constexpr int MAXD = 40;             // bisection depth the LDS interval stack can hold
+    constexpr int MAXD = EMME_MAX_DEPTH;  // bisection depth the LDS interval stack can hold
     extern __shared__ double lds_tab[];  // eta | g | b  (3N doubles) | per-group (mid, r) stack
 
     const DevParams& P = A.P;
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
         // (up to rounding far below the 1 % margin) is exactly depth < max_sub.
         bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
                      err > rel_abs + P.prec_goal;
-        if (split && (depth >= MAXD || item_intervals >= (1 << 18))) {  // flag and accept
+        if (split && (depth >= MAXD || item_intervals >= EMME_MAX_INTERVALS)) {  // flag and accept
             split = false;
             bad = 1;
         }
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     constexpr int GW = PTS == 15 ? 16 : 32;
     constexpr int NG = BT / GW;
     constexpr int CAP = 4 * BT;  // >= NG * (MAXD + 1)
-    constexpr int MAXD = 40;
+    constexpr int MAXD = EMME_MAX_DEPTH;
     static_assert(CAP >= NG * (MAXD + 1), "stack bound of the deepest-first walk");
     extern __shared__ double lds_tab[];  // eta | g | b (3N doubles) | CoopEnt stack[CAP]
     __shared__ int s_cnt[NG];
@@ -434,7 +457,7 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
             }
             n_intervals += n_take;
             int ntop = base + total;
-            if (ntop > CAP || n_intervals >= (1 << 18)) {  // flag and stop refining (block-uniform)
+            if (ntop > CAP || n_intervals >= EMME_MAX_INTERVALS) {  // flag and stop refining (block-uniform)
                 if (threadIdx.x == 0) s_bad = 1;
                 ntop = base;
             } else if (split && lane_in_group == 0) {
@@ -500,6 +523,7 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const No
                            const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                            const void* const ttab[2], const void* const wtab[2]) {
     AsmArgs A;
+    A.tiled = 0;
     A.P = L.P;
     A.tab = L.tab;
     A.pairs = (const ushort2*)L.pairs;
@@ -534,7 +558,7 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const No
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)L.nbatch), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
-                       (size_t)groups_per_block * 40 * sizeof(double2);
+                       (size_t)groups_per_block * EMME_MAX_DEPTH * sizeof(double2);
     if (L.gk_points == 15)
         hipLaunchKernelGGL((k_assemble<15, false>), grid, block, lds, stream, A);
     else
@@ -550,8 +574,9 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                 const void* const ttab[2], const void* const wtab[2], bool folded,
-                                hipStream_t stream) {
+                                hipStream_t stream, bool tiled) {
     AsmArgs A;
+    A.tiled = tiled ? 1 : 0;
     A.P = L.P;
     A.tab = L.tab;
     A.pairs = (const ushort2*)L.pairs;
@@ -603,11 +628,35 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
         return hipGetLastError();
     }
     const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
-                       (size_t)groups_per_block * 40 * sizeof(double2);
+                       (size_t)groups_per_block * EMME_MAX_DEPTH * sizeof(double2);
     if (L.gk_points == 15)
         hipLaunchKernelGGL((k_assemble<15, true>), grid, block, lds, stream, A);
     else
         hipLaunchKernelGGL((k_assemble<31, true>), grid, block, lds, stream, A);
+    return hipGetLastError();
+}
+
+
+// ---- the Bessel helper alone (tests / tooling) ---------------------------------------------------
+// util::bessel_i_alter_helper (include/functions.h:381-408) as the fill kernels evaluate it:
+// out = {y0, y1, mu + y0, Re z < 0 ? z : -z} per argument.
+namespace {
+__global__ void k_bessel_probe(const double2* z, int n, double2* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const cd zz = mk(z[k].x, z[k].y);
+    const double zabs = sqrt(norm2(zz));
+    cd y0, y1, mutot;
+    bessel_miller(rcp(zz), zabs, 1.0 / zabs, zz.x < 0.0, y0, y1, mutot);
+    out[4 * k + 0] = make_double2(y0.x, y0.y);
+    out[4 * k + 1] = make_double2(y1.x, y1.y);
+    out[4 * k + 2] = make_double2(mutot.x, mutot.y);
+    out[4 * k + 3] = zz.x < 0.0 ? make_double2(zz.x, zz.y) : make_double2(-zz.x, -zz.y);
+}
+}  // namespace
+hipError_t launch_bessel_probe(const double* z, int n, double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bessel_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const double2*)z, n,
+                       (double2*)out);
     return hipGetLastError();
 }
 

@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void k_phase_table(PhaseArgs A) {
         if (A.ttab[cls]) {
             const double2 t = A.ttab[cls][row];
             const double ax = fma(t.x, om.x, -(t.y * om.y)), ay = fma(t.x, om.y, t.y * om.x);
-            if (ax <= 700.0) {  // beyond: not representable (and never met where the integrand lives)
-                double sa, ca;
+            if (!(ax > 700.0)) {  // beyond: not representable (and never met where the integrand lives);
+                double sa, ca;    // a NaN omega goes through and poisons the integral, which flags it
                 sincos(ay, &sa, &ca);
                 const double ea = exp(ax);
                 ev = make_double2(ea * ca, ea * sa);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
             if (abs_tol == 0.0) abs_tol = rel_abs;
             bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
                          err > rel_abs + P.prec_goal;
-            if (split && item_intervals >= (1 << 18)) {
+            if (split && (depth >= EMME_MAX_DEPTH || item_intervals >= EMME_MAX_INTERVALS)) {
                 split = false;
                 bad = 1;
             }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     constexpr int H = (PTS + 1) / 2;
     constexpr int NODE_UNROLL = PTS == 15 ? 5 : 3;  // trips of the 3-node loop unrolled
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
-    constexpr int KD = 56;  // key layout: depth <= KD
+    constexpr int KD = 56;  // key layout: depth <= KD (>= EMME_MAX_DEPTH + 1)
     extern __shared__ double lds_raw[];  // eta | g | b | scale table
 
     const DevParams& P = A.P;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
                 if (abs_tol[m] == 0.0) abs_tol[m] = rel_abs;
                 bool split = depth < P.max_sub && err > abs_tol[m] * inv_scale + P.prec_goal &&
                              err > rel_abs + P.prec_goal;
-                if (split && (depth >= KD || count[m] >= (1 << 18))) {
+                if (split && (depth >= EMME_MAX_DEPTH || count[m] >= EMME_MAX_INTERVALS)) {
                     split = false;
                     bad = 1;
                 }
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
                 if (abs_tol == 0.0) abs_tol = rel_abs;
                 bool split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
                              err > rel_abs + P.prec_goal;
-                if (split && (depth >= KD || count >= (1 << 18))) {
+                if (split && (depth >= EMME_MAX_DEPTH || count >= EMME_MAX_INTERVALS)) {
                     split = false;
                     bad = 1;
                 }

@@ -9,6 +9,17 @@
 namespace emme {
 namespace {
 
+// Caps of the adaptive quadrature that the reference does not have.  Its only limit is the depth
+// integration_iteration_limit (`ldexp(scale, max_sub) > 0.99 (b - a)`, include/functions.h:240),
+// 100 in the shipped inputs; every fill kernel here additionally stops refining at depth
+// EMME_MAX_DEPTH (the interval is then pi/2 * 2^-40 = 1.4e-12 wide: a finite integrand of this
+// family is resolved long before -- deepest tree met in the tests and the bench: 21 -- and a NaN
+// never splits, its comparisons being false) or after EMME_MAX_INTERVALS intervals of one
+// integral, and flags the matrix (status -> EMME_ENUMERIC) instead of walking on.  The same two
+// numbers in every kernel, so that the flag does not depend on which kernel served the integral.
+constexpr int EMME_MAX_DEPTH = 40;
+constexpr int EMME_MAX_INTERVALS = 1 << 18;
+
 // per-lane node tables: lane r of a group -> (signed abscissa, Kronrod weight, Gauss weight)
 __device__ const double kX15[8] = {0.,
                                    0.20778495500789847,

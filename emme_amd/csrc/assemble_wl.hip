@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
     constexpr int H = (PTS + 1) / 2;
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     constexpr int GROUPS_PER_WAVE = 64 / GW;
-    constexpr int MAXD = 40;
+    constexpr int MAXD = EMME_MAX_DEPTH;
     extern __shared__ double lds_raw[];  // tables | interval stacks | node slots
 
     const DevParams& P = A.P;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
                 if (abs_tol == 0.0) abs_tol = rel_abs;
                 my_split = depth < P.max_sub && err > abs_tol * inv_scale + P.prec_goal &&
                            err > rel_abs + P.prec_goal;
-                if (my_split && (depth >= MAXD || item_intervals >= (1 << 18))) {
+                if (my_split && (depth >= MAXD || item_intervals >= EMME_MAX_INTERVALS)) {
                     my_split = false;
                     bad = 1;
                 }
@@ -325,7 +325,7 @@ hipError_t launch_assemble_wl(const AssembleLaunch& L, const int* act_idx, int n
     if (gx > 65535) gx = 65535;
     dim3 grid((unsigned)gx, (unsigned)chunks), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double) +
-                       (size_t)groups_per_block * 40 * sizeof(double2) +
+                       (size_t)groups_per_block * EMME_MAX_DEPTH * sizeof(double2) +
                        (size_t)256 * 4 * sizeof(double2);
     if (L.gk_points == 15)
         hipLaunchKernelGGL(k_assemble_wl<15>, grid, block, lds, stream, A);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,7 +46,7 @@ bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice;
 }
 
-enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2, K_DEFER = 3 };
+enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2, K_DEFER = 3, K_CACHE = 4 };
 
 }  // namespace
 }  // namespace emme
@@ -85,6 +86,9 @@ struct emme_ctx {
     void* d_wtab[2] = {nullptr, nullptr};      // moment-factor table per class (shared EM layout)
     bool em_shared = false;    // nm == 3: one record per (pair, interval, node), three moments per lane
     bool folded = true;        // records carry exp(A0); exp(T omega) comes from a per-launch phase table
+    bool tiled = false;        // electrostatic GK15: tiled record layout + dense (matrix-core) fill
+    void* d_btab = nullptr;    // weighted phase tables of the current launch (dense fill)
+    size_t btab_cap = 0;
     void* d_etab = nullptr;    // phase table of the current launch
     size_t etab_bytes = 0;
     int* h_lu_items = nullptr;     // blocked LU: the live matrices of the launch (pinned host / device)
@@ -195,6 +199,20 @@ void pool_free(void* p, size_t bytes, int device) {
     (void)hipSetDevice(device);
 }
 
+// host wall time of the cache allocations (hipMalloc of tens of GB: the cold cost of a context)
+struct AllocTimer {
+    emme_ctx* c;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool running = true;
+    explicit AllocTimer(emme_ctx* ctx) : c(ctx) {}
+    void stop() {
+        if (running)
+            c->acc.cache_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        running = false;
+    }
+    ~AllocTimer() { stop(); }
+};
+
 size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
 
 hipEvent_t get_event(emme_ctx* c) {
@@ -240,6 +258,8 @@ int drain_spans(emme_ctx* c) {
             c->acc.linstep_ms += ms, c->acc.linstep_launches++;
         else if (s.kind == K_DEFER)
             c->acc.deferred_ms += ms, c->acc.deferred_launches++;
+        else if (s.kind == K_CACHE)
+            c->acc.cache_build_ms += ms, c->acc.cache_build_launches++;
         else
             c->acc.other_ms += ms, c->acc.other_launches++;
         c->free_events.push_back(s.a);
@@ -269,8 +289,8 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(malloc_retry((void**)&c->d_actidx, sizeof(int) * nb));
     HIP_TRY(malloc_retry((void**)&c->d_chunks, sizeof(int) * 2 * nb));
     if (!c->d_rounds) {
-        HIP_TRY(malloc_retry((void**)&c->d_rounds, sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_rounds, 0, sizeof(unsigned long long)));
+        HIP_TRY(malloc_retry((void**)&c->d_rounds, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_rounds, 0, 16 * sizeof(unsigned long long)));
     }
     c->cap = nb;
     return EMME_OK;
@@ -407,12 +427,20 @@ int items_per_group_for(const emme_ctx* c, long units) {
 
 // items the node cache is indexed by: (pair, moment), or pairs alone in the shared EM layout
 long cache_items(const emme_ctx* c) { return (long)c->npairs * (c->em_shared ? 1 : c->nm); }
+// bytes of one part of the node cache in this context's record layout
+size_t cache_part_bytes(const emme_ctx* c, int gk_points, const NodeCacheGeom& g, int part) {
+    return c->tiled ? node_cache_bytes_tiled(c->npairs, g, part) : node_cache_bytes(gk_points, cache_items(c), g, part);
+}
+hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCacheGeom& g, int part, int cls, void* recs) {
+    const double omi = cls == 0 ? 1.0 : -1.0;
+    if (c->tiled) return launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream);
+    return launch_node_cache(L, g, part, omi, recs, c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->folded, c->stream);
+}
 
 // Make sure the main part of the node cache of contour class `cls` (0: omi=+1, 1: omi=-1)
 // exists.  Returns false (and disables the cache) if it does not fit the budget.
 bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->cache_depth == -2) return false;
-    const long nitems = cache_items(c);
     const double budget = c->cache_budget_gb * (double)(1 << 30);
     if (c->cache_depth == -1) {
         // full tree to depth dfull + the fixed subtree under the rightmost depth-5 node (that is
@@ -423,7 +451,7 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         for (const auto& o : options) {
             NodeCacheGeom g{};
             g.dfull = o[0], g.nsub = 1, g.rd[0] = o[1], g.dd[0] = o[2], g.rp[0] = (1ull << o[1]) - 1ull;
-            if ((double)node_cache_bytes(L.gk_points, nitems, g, -1) <= 0.25 * budget) {
+            if ((double)cache_part_bytes(c, L.gk_points, g, -1) <= 0.25 * budget) {
                 c->cache_geom = g;
                 found = true;
                 break;
@@ -437,7 +465,8 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         c->cache_max_intervals = node_cache_intervals(c->cache_geom) + (NODE_CACHE_MAX_SUB - 1) * 511;
     }
     if (c->d_recs[cls]) return true;
-    const size_t bytes = node_cache_bytes(L.gk_points, nitems, c->cache_geom, -1);
+    const size_t bytes = cache_part_bytes(c, L.gk_points, c->cache_geom, -1);
+    AllocTimer at(c);
     if (c->cache_bytes_used + (double)bytes > budget ||
         pool_alloc(&c->d_recs[cls], bytes, c->device) != hipSuccess ||
         malloc_retry(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
@@ -451,11 +480,11 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         c->cache_depth = -2;  // fall back to the on-the-fly kernels for good
         return false;
     }
+    at.stop();
     c->cache_bytes_used += (double)bytes;
     c->recs_bytes[cls] = bytes;
-    ScopedSpan s(c, K_OTHER);
-    if (launch_node_cache(L, c->cache_geom, -1, cls == 0 ? 1.0 : -1.0, c->d_recs[cls], c->d_ttab[cls],
-                          c->d_wtab[cls], c->d_scale, c->folded, c->stream) != hipSuccess) {
+    ScopedSpan s(c, K_CACHE);
+    if (build_cache_part(c, L, c->cache_geom, -1, cls, c->d_recs[cls]) != hipSuccess) {
         c->cache_depth = -2;
         return false;
     }
@@ -492,9 +521,9 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
     } else if (c->d_recs_ext[cls][k - 1]) {
         return;  // already there (the deferral was for an interval deeper than the subtree)
     }
-    const long nitems = cache_items(c);
     const double budget = c->cache_budget_gb * (double)(1 << 30);
-    const size_t eb = node_cache_bytes(L.gk_points, nitems, g, k - 1);
+    const size_t eb = cache_part_bytes(c, L.gk_points, g, k - 1);
+    AllocTimer at(c);
     if (c->cache_bytes_used + (double)eb > budget ||
         pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
         (void)hipGetLastError();
@@ -503,13 +532,12 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
         if (fresh) g.nsub = k;  // nothing built: forget the registration
         return;
     }
+    at.stop();
     c->cache_bytes_used += (double)eb;
     c->recs_ext_bytes[cls][k - 1] = eb;
     {
-        ScopedSpan s(c, K_OTHER);
-        if (launch_node_cache(L, g, k - 1, cls == 0 ? 1.0 : -1.0, c->d_recs_ext[cls][k - 1], c->d_ttab[cls],
-                              c->d_wtab[cls], c->d_scale, c->folded, c->stream) != hipSuccess)
-            c->ext_failed = true;
+        ScopedSpan s(c, K_CACHE);
+        if (build_cache_part(c, L, g, k - 1, cls, c->d_recs_ext[cls][k - 1]) != hipSuccess) c->ext_failed = true;
     }
     if (std::getenv("EMME_DEBUG"))
         fprintf(stderr, "[emme] node cache: subtree %d (depth %d path %llx, to depth %d) built for class %d, %.1f GiB in use\n",
@@ -610,7 +638,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         // that sit a round out cost little there, so its chunks are always full and each group
         // takes three items (measured optimum: 86.5 ms vs 104 with the policy below)
         static const bool union_env = !(std::getenv("EMME_UNION") && std::atoi(std::getenv("EMME_UNION")) == 0);
-        const bool union_walk = union_env && c->folded && c->nm == 1 && L.gk_points == 15;
+        const bool union_walk = (union_env || c->tiled) && c->folded && c->nm == 1 && L.gk_points == 15;
         // Omega chunks of unequal size.  Every lane walks ONE omega's trees, so an
         // omega whose integrals need 3x the intervals keeps its lane busy 3x longer than its
         // neighbours'.  A chunk of n omegas gives each of them gw/n lanes per group: expensive
@@ -649,8 +677,30 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_lane, hipMemcpyHostToDevice, c->stream));
         if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
-        c->last_fill_mode = union_walk ? 3 : 2;
-        if (n_lane && c->folded) {
+        c->last_fill_mode = c->tiled ? 4 : (union_walk ? 3 : 2);
+        if (n_lane && c->tiled) {
+            // dense fill: weighted phase tables for every cached interval and omega chunk, then one wave
+            // per (16-pair tile, 16-omega chunk); chunk c = positions 16 c .. of the cost-sorted list
+            const int n_int = node_cache_intervals(c->cache_geom);
+            const int nch = (n_lane + 15) / 16;
+            const size_t need = btab_bytes(n_int, nch);
+            if (need > c->btab_cap) {
+                if (c->d_btab) (void)hipFree(c->d_btab);
+                c->d_btab = nullptr, c->btab_cap = 0;
+                HIP_TRY(malloc_retry(&c->d_btab, need + need / 4));
+                c->btab_cap = need + need / 4;
+            }
+            {
+                ScopedSpan s(c, K_OTHER);
+                HIP_TRY(launch_btab(n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_btab, c->stream));
+            }
+            {
+                ScopedSpan s(c, K_ASM);
+                HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
+                                              c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
+                                              c->d_rounds, c->stream));
+            }
+        } else if (n_lane && c->folded) {
             // phase table of this launch: exp(T omega) for every cached interval, node and omega
             const int n_int = node_cache_intervals(c->cache_geom);
             const size_t need = (size_t)n_lane * n_int * gw * 2 * sizeof(double);
@@ -664,7 +714,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             HIP_TRY(launch_phase_table(L.gk_points, n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_etab,
                                        c->stream));
         }
-        if (n_lane) {
+        if (n_lane && !c->tiled) {
             ScopedSpan s(c, K_ASM);
             const void* etab = c->folded ? c->d_etab : nullptr;
             if (c->em_shared)
@@ -679,7 +729,8 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         if (n_lane) {
             ScopedSpan s(c, K_DEFER);
             HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
-                                         c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream));
+                                         c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream,
+                                         c->tiled));
         }
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
@@ -717,7 +768,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
 extern "C" {
 
 const char* emme_last_error(void) { return g_error.c_str(); }
-int emme_version(void) { return 1; }
+int emme_version(void) { return 2; }
 
 int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     if (!p || !out) return EMME_EINVAL;
@@ -763,6 +814,15 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->em_shared = !es && !(std::getenv("EMME_EM_SHARED") && std::atoi(std::getenv("EMME_EM_SHARED")) == 0);
     // EMME_PHASE_TABLE=0: unfolded records and exp(A0 + T omega) per (pair, node, omega) in the fill
     c->folded = !(std::getenv("EMME_PHASE_TABLE") && std::atoi(std::getenv("EMME_PHASE_TABLE")) == 0);
+    // EMME_DENSE=1: electrostatic GK15 on folded records through the tiled layout + dense fill on the
+    // FP64 matrix cores (assemble_dense.hip) instead of the union walk.  EXPERIMENTAL, off by default:
+    // faster on batches whose omegas have overlapping trees (the bootstrap fills of the bench: 1.17 /
+    // 1.37 ms against 1.58 / 2.18), slower as soon as chains wander.  It carries the
+    // safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature goal is tighter
+    // than 1e-9 never take it.
+    c->tiled = es && p->integration_start_points == 15 && c->folded && p->integration_accuracy >= 1e-9 &&
+               (std::getenv("EMME_DENSE") && std::atoi(std::getenv("EMME_DENSE")) == 1) &&
+               !(std::getenv("EMME_UNION") && std::atoi(std::getenv("EMME_UNION")) == 0);
 
     DevParams& P = c->P;
     std::vector<double> tab(3 * (size_t)N);
@@ -819,7 +879,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
         if (p) (void)hipFree((void*)p);
     };
     F(c->d_tab), F(c->d_pairs), F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active),
-        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_chunks), F(c->d_M),
+        F(c->d_iters), F(c->d_info), F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks), F(c->d_M),
         F(c->d_Mold),
         F(c->d_Mp), F(c->d_work), F(c->d_iterates), F(c->d_rounds);
     for (int k = 0; k < 2; ++k) {
@@ -830,6 +890,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     }
     F(c->d_scale);
     F(c->d_etab);
+    F(c->d_btab);
     F(c->d_lu_scratch);
     F(c->d_lu_items);
     if (c->h_lu_items) (void)hipHostFree(c->h_lu_items);
@@ -870,9 +931,21 @@ int emme_ctx_profile_read(emme_ctx_t* c, emme_profile_t* out, int reset) {
     if (rc) return rc;
     c->acc.integrand_evals = c->acc.gk_intervals * c->p.integration_start_points;
     if (c->d_rounds) {
-        unsigned long long r = 0;
-        HIP_TRY(hipMemcpy(&r, c->d_rounds, sizeof r, hipMemcpyDeviceToHost));
-        c->acc.union_rounds = (long long)r;
+        unsigned long long r[16] = {};
+        HIP_TRY(hipMemcpy(r, c->d_rounds, sizeof r, hipMemcpyDeviceToHost));
+        if (std::getenv("EMME_DEBUG_STAMPS") && r[8])  // diagnostic build (EMME_DENSE_STAMPS) only
+            fprintf(stderr, "[emme] dense stamps: select %.3g  dense %.3g  sparse %.3g  decide %.3g  task total %.3g  "
+                    "longest task %.3g cycles; per round: select %.0f dense %.0f sparse %.0f decide %.0f\n",
+                    (double)r[4], (double)r[5], (double)r[6], (double)r[7], (double)r[8], (double)r[9],
+                    (double)r[4] / (double)(r[0] + r[1] + 1), (double)r[5] / (double)(r[0] + 1),
+                    (double)r[6] / (double)(r[1] + 1), (double)r[7] / (double)(r[0] + r[1] + 1));
+        if (c->tiled) {
+            c->acc.union_rounds = (long long)(r[0] + r[1]);
+            c->acc.dense_rounds = (long long)r[0], c->acc.sparse_rounds = (long long)r[1];
+            c->acc.sparse_columns = (long long)r[2], c->acc.tile_tasks = (long long)r[3];
+        } else {
+            c->acc.union_rounds = (long long)r[0];
+        }
         if (reset) HIP_TRY(hipMemset(c->d_rounds, 0, sizeof r));
     }
     *out = c->acc;
@@ -935,13 +1008,17 @@ int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* 
     }
     const size_t bytes = (size_t)n * n * 2 * sizeof(double) * nbatch;
     double *dA = A, *dB = B;
-    if (!devA) {
-        HIP_TRY(malloc_retry((void**)&dA, bytes));
-        if (malloc_retry((void**)&dB, bytes) != hipSuccess) {
-            (void)hipFree(dA);
-            set_error("hipMalloc failed");
-            return EMME_ENOMEM;
+    struct Staging {  // device copies of host operands, released on every way out
+        double *a = nullptr, *b = nullptr;
+        ~Staging() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
         }
+    } st;
+    if (!devA) {
+        HIP_TRY(malloc_retry((void**)&st.a, bytes));
+        HIP_TRY(malloc_retry((void**)&st.b, bytes));
+        dA = st.a, dB = st.b;
         HIP_TRY(hipMemcpyAsync(dA, A, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(dB, B, bytes, hipMemcpyHostToDevice, c->stream));
     }
@@ -952,10 +1029,6 @@ int emme_trace_solve_batch(emme_ctx_t* c, int n, int nbatch, double* A, double* 
     HIP_TRY(hipMemcpyAsync(tr, c->d_tr, sizeof(double) * 2 * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(info, c->d_info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!devA) {
-        (void)hipFree(dA);
-        (void)hipFree(dB);
-    }
     return EMME_OK;
 }
 
@@ -1235,6 +1308,8 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         // per item (the reference would carry the NaN to its "eigenvalue": "NaN" record,
         // src/main.cpp:311-316); the other chains of the batch are unaffected
         if (stv[b] != 0 && info[b] == 0) info[b] = EMME_ENUMERIC;
+        // whatever the cause, a non-finite omega is never handed back as a root
+        if (info[b] == 0 && !(std::isfinite(roots[2 * b]) && std::isfinite(roots[2 * b + 1]))) info[b] = EMME_ENUMERIC;
     }
     // The multi-workgroup LU needs its workgroups resident together; if something else held
     // compute units for seconds (a foreign kernel on a shared device) a hand-over wait timed out
@@ -1249,6 +1324,31 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             return emme_solve_roots(c, guesses, n, tol, step_limit, roots, iters, info, iterates);
         }
     }
+    return EMME_OK;
+}
+
+int emme_bessel_batch(const double* z, int n, double* out) {
+    if (!z || !out || n < 1) return EMME_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (the MI355X path has no CPU fallback)");
+        return EMME_EDEVICE;
+    }
+    double *dz = nullptr, *dout = nullptr;
+    struct Free {
+        double*& a;
+        double*& b;
+        ~Free() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+        }
+    } guard{dz, dout};
+    HIP_TRY(hipMalloc((void**)&dz, sizeof(double) * 2 * n));
+    HIP_TRY(hipMalloc((void**)&dout, sizeof(double) * 8 * n));
+    HIP_TRY(hipMemcpy(dz, z, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    HIP_TRY(launch_bessel_probe(dz, n, dout, nullptr));
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 8 * n, hipMemcpyDeviceToHost));
     return EMME_OK;
 }
 

@@ -171,6 +171,16 @@ JsonValue solve_once(const JsonValue& input, cplx& omega, const std::string& mat
             << ", so the solution could not be computed.";
         throw std::runtime_error(oss.str());
     }
+    if (info < 0) {
+        // Failures the reference does not have a code for.  It would carry a non-finite integral
+        // into omega and end with a NaN eigenvalue, or (singular LAPACK step) throw; either way the
+        // scan records {"eigenvalue":"NaN","reason":...} (src/main.cpp:311-318) and does NOT
+        // continue the next scan point from this omega.  Same here.
+        throw std::runtime_error(
+            info == EMME_ENUMERIC
+                ? "Integration failed: non-finite integral or quadrature depth cap reached (EMME_ENUMERIC)."
+                : "Linear solve failed on the device (EMME_EDEVICE).");
+    }
     const int dim = emme_ctx_dim(ctx);
     std::vector<cplx> M((size_t)dim * dim), vec(dim);
     if (emme_ctx_get_matrix(ctx, 0, reinterpret_cast<double*>(M.data())) != EMME_OK)

@@ -83,7 +83,24 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                 const void* const ttab[2], const void* const wtab[2], bool folded,
-                                hipStream_t stream);
+                                hipStream_t stream, bool tiled = false);
+
+// ---- dense (matrix-core) fill of electrostatic GK15 contexts: assemble_dense.hip ------------------
+// tiled record layout: see node_cache.hpp
+size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part);
+hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
+                                   void* recs, void* ttab, double* scale, hipStream_t stream);
+// weighted phase tables of one launch: btab_bytes(cached intervals, ceil(n_act / 16))
+size_t btab_bytes(int nslots, int nchunks);
+hipError_t launch_btab(int nslots, const void* const ttab[2], const double* omega, const int* act_idx,
+                       int n_act, void* btab, hipStream_t stream);
+// act_idx: the launch's omegas, cost-sorted; chunk c = positions 16 c .. 16 c + 15.  stats (nullable):
+// 4 counters (dense rounds, sparse rounds, sparse columns, tile tasks)
+hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
+                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1], const double* scale,
+                                 const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
+                                 unsigned long long* defer_info, const int* act_idx, int n_act,
+                                 unsigned long long* stats, hipStream_t stream);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
@@ -128,5 +145,8 @@ hipError_t launch_retire(int nbatch, int* active, hipStream_t stream);
 // Mp = (M - Mold) / domega, elementwise (include/solver.h:54-57), for active items.
 hipError_t launch_secant(int nbatch, size_t nn, const double* M, const double* Mold,
                          const double* domega, const int* active, double* Mp, hipStream_t stream);
+
+// bessel_miller on n complex arguments (device pointers): out[4n] = y0, y1, mu + y0, -/+ z
+hipError_t launch_bessel_probe(const double* z, int n, double* out, hipStream_t stream);
 
 }  // namespace emme

@@ -293,6 +293,13 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         return J < n ? a + (size_t)prow_ * n + J : bb + (size_t)prow_ * n + (J - n);
     };
 
+    // Retire the matrix for every workgroup working on it: ABORT goes into all eight hand-over
+    // words with a MAXIMUM (publications are maxima too, so a later publication cannot erase it,
+    // and the arrival counters only grow), so whichever word a workgroup waits on, it leaves at once.
+    auto abort_all = [&]() {
+        for (int q = 0; q < 8; ++q)
+            __hip_atomic_fetch_max(flag_pub + q, ABORT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
     // whole-workgroup wait for *flag >= v; false on abort / time-out (the matrix is retired)
     auto wg_wait = [&](int* flag, int v) -> bool {
         if (tid == 0) sh.go = spin_ge(flag, v, ctl.spin_limit);
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             if (tid == 0) {
                 tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
                 info_out[b] = INFO_TIMEOUT;
-                __hip_atomic_store(flag_pub, ABORT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                abort_all();
             }
             return false;
         }
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             }
             __syncthreads();  // (every thread's stores are performed; thread 0 releases them)
             if (a_helper && tid == 0)
-                __hip_atomic_store(flag_pub + 2 + role, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(flag_pub + 2 + role, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else
     for (int k0 = 0; k0 < n; k0 += NB) {
@@ -496,8 +503,8 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                 }
             }
             __syncthreads();  // every thread's stores are performed; thread 0 releases them
-            if (tid == 0)
-                __hip_atomic_store(flag_pub, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0)  // (a maximum, not a store: an ABORT already there must survive)
+                __hip_atomic_fetch_max(flag_pub, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- trailing update, one column per lane -------------------------------------------
         // (thread coordinates recomputed from an opaque copy: whatever the update derives from
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         if (tid == 0) {
             tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
             info_out[b] = sh.info;
-            if (SPLIT) __hip_atomic_store(flag_pub, ABORT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (SPLIT) abort_all();
         }
         return;
     }

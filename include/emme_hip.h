@@ -59,11 +59,19 @@ typedef struct emme_profile {
     long long integrand_evals; /* = intervals * integration_start_points             */
     long long matrices;       /* matrices assembled                                  */
     long long union_rounds;   /* omega-lane kernel: interval rounds walked by lane groups */
+    double cache_build_ms;    /* k_node_cache launches (node-record cache, once per context) */
+    long cache_build_launches;
+    double cache_alloc_ms;    /* host wall time spent allocating the cache buffers (hipMalloc) */
+    /* dense (matrix-core) fill: interval rounds of the (16 pairs x 16 omegas) tile tasks */
+    long long dense_rounds;   /* served by 48 v_mfma_f64_16x16x4_f64 each                 */
+    long long sparse_rounds;  /* served on the vector ALU, one omega column at a time      */
+    long long sparse_columns;
+    long long tile_tasks;
 } emme_profile_t;
 
 const char* emme_last_error(void);
 int emme_params_sizeof(void);
-int emme_version(void);
+int emme_version(void); /* 2: emme_profile_t grew the cache_* fields; emme_comm_*, emme_gather_roots */
 
 /* JSON text -> raw + derived parameters.  Reproduces the reference parser's grammar
  * (a number token is a float only if it contains '.', else atoi; no string escapes)
@@ -79,6 +87,11 @@ int emme_tables(const emme_params_t* p, double* eta, double* g, double* b, doubl
 /* SingularityHandler weight W(i,j) (reference src/singularity_handler.cpp:3-24). */
 double emme_weight(int n, int i, int j);
 
+/* The Bessel helper alone, evaluated on the device exactly as the fill kernels do (tests and
+ * tooling): util::bessel_i_alter_helper (reference include/functions.h:381-408) for n complex
+ * arguments z (2n doubles, host); out: 8n doubles = {y0, y1, mu + y0, Re z < 0 ? z : -z} each. */
+int emme_bessel_batch(const double* z, int n, double* out);
+
 /* One context per (device, parameter set). device < 0 => current device. */
 int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out);
 void emme_ctx_destroy(emme_ctx_t* ctx);
@@ -90,7 +103,8 @@ void emme_release_pooled_memory(void);
 int emme_ctx_set_stream(emme_ctx_t* ctx, void* hip_stream);
 int emme_ctx_dim(const emme_ctx_t* ctx); /* N if beta_e == 0 else 2N */
 /* Kernel family used by the last fill: 0 lanes-are-nodes, 1 omega-lane, 2 HBM node cache
- * (independent lanes), 3 HBM node cache + phase table, union walk. */
+ * (independent lanes), 3 HBM node cache + phase table, union walk, 4 HBM node cache (tiled) +
+ * dense fill on the FP64 matrix cores. */
 int emme_ctx_fill_mode(const emme_ctx_t* ctx);
 /* GiB of HBM currently held by the node-record cache (0 if none). */
 double emme_ctx_node_cache_gib(const emme_ctx_t* ctx);
@@ -158,6 +172,28 @@ void emme_free(void* p);
  * other direction.  Returns the number of values (<= max_values). */
 int emme_scan_values(double head, double step, double tail0, double tail1, double* values,
                      int* turning_flags, int max_values);
+
+/* ---- multi-GPU scan: the one collective -------------------------------------------------------
+ * The (parameter set, omega guess) items of a scan are independent Newton chains.  The reference
+ * walks them sequentially in one process (src/main.cpp:264-324); here item k of n_total goes to
+ * rank k mod world (one process per GPU, its own context), nothing is exchanged while iterating,
+ * and ONE RCCL all-gather (ncclAllGather over xGMI, 32 B per item) hands every rank all roots.
+ * RCCL is bound at run time; a process that never calls these does not load it. */
+#define EMME_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+typedef struct emme_comm emme_comm_t;
+/* Rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks out of band
+ * (a file, a socket, MPI, torch.distributed's store ...). */
+int emme_comm_unique_id(unsigned char* id /* EMME_COMM_ID_BYTES */);
+/* Collective over all `world` ranks (ncclCommInitRank). device < 0 => current device. */
+int emme_comm_create(const unsigned char* id, int rank, int world, int device, emme_comm_t** out);
+void emme_comm_destroy(emme_comm_t* comm);
+/* Collective.  In: this rank's results in the order of its share (items rank, rank+world, ...),
+ * n_local of them; n_local must be the round-robin share of n_total (EMME_EINVAL otherwise,
+ * checked before the collective).  Out (host, on every rank): all n_total results in item order.
+ * hip_stream: stream for the copies and the collective (NULL = default). */
+int emme_gather_roots(emme_comm_t* comm, void* hip_stream, const double* roots /* 2*n_local */,
+                      const int* iters, const int* info, int n_local, int n_total,
+                      double* roots_all /* 2*n_total */, int* iters_all, int* info_all);
 
 #ifdef __cplusplus
 }

@@ -257,6 +257,15 @@ void oracle_depth_hist(long* out64, int reset) {
     }
 }
 
+/* diagnostic: the evaluated intervals of the calling thread's next integrals, in evaluation
+ * order, as depth << 56 | index (index = position of the interval among the 2^depth of its depth) */
+static __thread long* g_trace_buf = 0;
+static __thread long g_trace_cap = 0, g_trace_n = 0;
+void oracle_trace_set(long* buf, long cap) {
+    g_trace_buf = buf, g_trace_cap = cap, g_trace_n = 0;
+}
+long oracle_trace_count(void) { return g_trace_n; }
+
 /* x -> f(tan x)/cos^2 x, include/functions.h:313-316 */
 static inline cplx mapped(integrand_fn f, void* ctx, double x) {
     const double c = cos(x);
@@ -310,6 +319,11 @@ static long gk_adaptive_0_inf(integrand_fn f, void* ctx, double rel_tol, double 
         {
             int dd = (int)(log2((b - a) / (r - l)) + 0.5);
             if (dd >= 0 && dd < 64) ++g_depth_hist[dd];
+            if (g_trace_buf) {
+                if (g_trace_n < g_trace_cap && dd >= 0 && dd < 56)
+                    g_trace_buf[g_trace_n] = ((long)dd << 56) | (long)(l / (b - a) * ldexp(1.0, dd) + 0.5);
+                ++g_trace_n;
+            }
         }
         if (fpclassify(abs_tol) == FP_ZERO) abs_tol = cabs(c_scale(integral, rel_tol));
         if (ldexp(scale, (int)max_sub) > 0.99 * (b - a) && err > abs_tol * inv_scale + prec_goal &&

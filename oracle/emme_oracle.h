@@ -69,6 +69,11 @@ int oracle_solve_root(const emme_params_t* p, double gre, double gim, int nthrea
                       int recompute, double* root2, double* iterates, double* M_final,
                       long* total_intervals);
 
+/* diagnostic: record the intervals the calling thread's integrals evaluate (depth << 56 | index,
+ * evaluation order) into buf; buf = NULL switches it off.  oracle_trace_count = intervals seen. */
+void oracle_trace_set(long* buf, long cap);
+long oracle_trace_count(void);
+
 /* diagnostic histogram of evaluated intervals by bisection depth (single-threaded runs) */
 void oracle_depth_hist(long* out64, int reset);
 

@@ -393,6 +393,12 @@ KERNEL_MODES = {
     # HBM node cache, folded records + phase table; electrostatic GK15: union-walk kernel, EM / GK31:
     # independent lanes (the defaults); uncached integrals via the work list
     "cached": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1"},
+    # electrostatic GK15 cases through the experimental dense (matrix-core) fill on the tiled cache
+    # layout: default routing, every round on the vector path, every round on the matrix cores
+    "cached-dense": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1"},
+    "cached-dense-all-sparse": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1", "EMME_DENSE_MIN_COLS": "17"},
+    "cached-dense-all-mfma": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1", "EMME_DENSE_MIN_COLS": "1"},
+    "cached-dense-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_DENSE": "1"},
     # the same with the independent-lane kernel for every case
     "cached-independent": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
     # unfolded records, exp(A0 + T omega) evaluated per (pair, node, omega) in the fill
