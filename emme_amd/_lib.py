@@ -101,6 +101,8 @@ def load():
     lib.emme_ctx_fill_mode.argtypes = [P]
     lib.emme_ctx_node_cache_gib.argtypes = [P]
     lib.emme_ctx_node_cache_gib.restype = C.c_double
+    lib.emme_ctx_cache_settle.argtypes = [P, P, C.c_int, P]
+    lib.emme_ctx_cache_state.argtypes = [P, P, P, P]
     lib.emme_ctx_profile_enable.argtypes = [P, C.c_int]
     lib.emme_ctx_profile_read.argtypes = [P, C.POINTER(Profile), C.c_int]
     lib.emme_assemble_batch.argtypes = [P, P, C.c_int, P, P]
@@ -336,6 +338,20 @@ class Context:
 
     def node_cache_gib(self) -> float:
         return self.lib.emme_ctx_node_cache_gib(self.h)
+
+    def cache_settle(self, omegas) -> int:
+        """Grow the node cache to its final shape for these omegas (the canonical state); returns
+        the number of fills it took."""
+        w = _c128(np.atleast_1d(omegas))
+        n = C.c_int(0)
+        _check(self.lib.emme_ctx_cache_settle(self.h, w.ctypes.data, w.shape[0], C.byref(n)))
+        return n.value
+
+    def cache_state(self):
+        """(depth of the fully cached tree, cached subtrees, GiB held)."""
+        d, k, g = C.c_int(0), C.c_int(0), C.c_double(0)
+        _check(self.lib.emme_ctx_cache_state(self.h, C.byref(d), C.byref(k), C.byref(g)))
+        return d.value, k.value, g.value
 
     def profile(self, on=True):
         _check(self.lib.emme_ctx_profile_enable(self.h, int(on)))

@@ -99,9 +99,16 @@ struct emme_ctx {
     int n_cu = 256;                // compute units of the device
     int last_lu_nwg = 1;           // workgroups per matrix of the last LU launch
     bool lu_one_wg = false;        // a hand-over of the multi-workgroup LU timed out once: never again
-    int* p_act = nullptr;          // pinned host copies of d_active / d_intervals: the Newton loop
-    unsigned long long* p_iv = nullptr;  // fetches them without a stream synchronisation of its own
+    int* p_act = nullptr;          // pinned host copies of d_active / d_intervals / omega / the deferred
+    unsigned long long* p_iv = nullptr;  // count, WRITTEN BY KERNELS (k_retire, k_newton_update): the
+    double* p_w = nullptr;         // Newton loop reads them after its one synchronisation per step
+    unsigned int* p_deferred = nullptr;
     int p_cap = 0;
+    bool pub_valid = false;        // last_deferred holds the previous fill's count (from p_deferred)
+    int* p_lists = nullptr;        // pinned staging of the per-launch lists (omega order | chunks), two
+    int p_lists_cap = 0;           // slots used in turn; k_stage_ints moves a slot to device memory
+    unsigned int p_lists_turn = 0;
+    unsigned int lu_items_turn = 0;
     bool ext_failed = false;
     unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
     double cache_bytes_used = 0.0;
@@ -288,6 +295,19 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(malloc_retry((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
     HIP_TRY(malloc_retry((void**)&c->d_actidx, sizeof(int) * nb));
     HIP_TRY(malloc_retry((void**)&c->d_chunks, sizeof(int) * 2 * nb));
+    {
+        if (c->p_act) (void)hipHostFree(c->p_act);
+        if (c->p_iv) (void)hipHostFree(c->p_iv);
+        if (c->p_w) (void)hipHostFree(c->p_w);
+        if (c->p_lists) (void)hipHostFree(c->p_lists);
+        c->p_act = nullptr, c->p_iv = nullptr, c->p_w = nullptr, c->p_lists = nullptr, c->p_cap = 0, c->p_lists_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->p_act, sizeof(int) * nb));
+        HIP_TRY(hipHostMalloc((void**)&c->p_iv, sizeof(unsigned long long) * nb));
+        HIP_TRY(hipHostMalloc((void**)&c->p_w, sizeof(double) * 2 * nb));
+        HIP_TRY(hipHostMalloc((void**)&c->p_lists, sizeof(int) * 2 * 3 * nb));  // 2 slots x (order | chunks)
+        if (!c->p_deferred) HIP_TRY(hipHostMalloc((void**)&c->p_deferred, sizeof(unsigned int)));
+        c->p_cap = nb, c->p_lists_cap = 3 * nb;
+    }
     if (!c->d_rounds) {
         HIP_TRY(malloc_retry((void**)&c->d_rounds, 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(c->d_rounds, 0, 16 * sizeof(unsigned long long)));
@@ -336,20 +356,23 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
         }
         // dense list of the live matrices (h_active: host copy of `active`, null = all live)
         int n_live = nbatch;
+        int* lu_slot = nullptr;
         if (h_active) {
             if (nbatch > c->lu_items_cap) {
                 if (c->d_lu_items) (void)hipFree(c->d_lu_items);
                 if (c->h_lu_items) (void)hipHostFree(c->h_lu_items);
                 c->d_lu_items = nullptr, c->h_lu_items = nullptr, c->lu_items_cap = 0;
                 hipError_t e = hipMalloc((void**)&c->d_lu_items, sizeof(int) * nbatch);
-                // pinned: the upload must not wait for the work queued on the stream
-                if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_lu_items, sizeof(int) * nbatch);
+                // pinned, two slots used in turn: the device reads a slot (k_stage_ints) while the host
+                // may already be writing the next launch's list
+                if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_lu_items, sizeof(int) * 2 * nbatch);
                 if (e != hipSuccess) return e;
                 c->lu_items_cap = nbatch;
             }
+            lu_slot = c->h_lu_items + (size_t)(c->lu_items_turn++ & 1u) * c->lu_items_cap;
             n_live = 0;
             for (int b = 0; b < nbatch; ++b)
-                if (h_active[b]) c->h_lu_items[n_live++] = b;
+                if (h_active[b]) lu_slot[n_live++] = b;
             if (n_live == 0) return hipSuccess;
         }
         int nwg = 1;
@@ -368,8 +391,7 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
         c->last_lu_nwg = nwg;
         const int* d_items = nullptr;
         if (nwg > 1 && h_active) {
-            hipError_t e = hipMemcpyAsync(c->d_lu_items, c->h_lu_items, sizeof(int) * n_live,
-                                          hipMemcpyHostToDevice, c->stream);
+            hipError_t e = launch_stage_ints(lu_slot, c->d_lu_items, n_live, nullptr, 0, c->stream);
             if (e != hipSuccess) return e;
             d_items = c->d_lu_items;
         }
@@ -447,8 +469,15 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         // where ordinary damped roots refine); the largest that leaves half the budget free
         static const int options[][3] = {{8, 5, 13}, {7, 5, 13}, {6, 5, 13}, {6, 5, 12}, {6, 5, 11},
                                          {5, 4, 10}, {5, 4, 9},  {4, 3, 7},  {3, 2, 5}};
+        // A cache that reaches less deep than depth 5 sends most integrals of a damped omega to the
+        // from-scratch kernel and is SLOWER than no cache at all (measured, N = 1024, where only depth 4
+        // fits: 83 omega-points/s with that cache against 335 through the omega-lane kernel,
+        // profiles/r02_size_sweep.jsonl): below that the context runs uncached (EMME_CACHE_MIN_DEPTH)
+        const char* md = std::getenv("EMME_CACHE_MIN_DEPTH");
+        const int min_depth = md ? std::atoi(md) : 5;
         bool found = false;
         for (const auto& o : options) {
+            if (o[0] < min_depth) break;
             NodeCacheGeom g{};
             g.dfull = o[0], g.nsub = 1, g.rd[0] = o[1], g.dd[0] = o[2], g.rp[0] = (1ull << o[1]) - 1ull;
             if ((double)cache_part_bytes(c, L.gk_points, g, -1) <= 0.25 * budget) {
@@ -567,7 +596,6 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     L.intervals = c->d_intervals;
     L.status = c->d_status;
     L.rounds = c->d_rounds;
-    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));  // previous upload of h_actidx done
     std::vector<int>& idx = c->h_actidx;
     idx.clear();
     for (int b = 0; b < nbatch; ++b)
@@ -593,8 +621,11 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         // the previous cached fill deferred a sizeable share of its integrals: look at which
         // intervals they were missing and cache a subtree around the most frequent one(s)
         if (use_cache && c->d_worklist_count && c->d_defer_info) {
-            HIP_TRY(hipMemcpyAsync(&c->last_deferred, c->d_worklist_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (!c->pub_valid) {  // (the Newton loop gets the count from k_retire through pinned memory)
+                HIP_TRY(hipMemcpyAsync(&c->last_deferred, c->d_worklist_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+            c->pub_valid = false;
             if (c->last_deferred >= 32) {
                 const size_t cnt = std::min<size_t>(c->last_deferred, 1u << 16);
                 std::vector<unsigned long long> info(cnt);
@@ -674,8 +705,13 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             const int ipg_few = e1 ? std::atoi(e1) : 2, few = e2 ? std::atoi(e2) : 3;
             if (nchunks <= few) L.items_per_group = std::max(1, ipg_few);
         }
-        if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_lane, hipMemcpyHostToDevice, c->stream));
-        if (n_lane) HIP_TRY(hipMemcpyAsync(c->d_chunks, ch.data(), sizeof(int) * ch.size(), hipMemcpyHostToDevice, c->stream));
+        if (n_lane) {
+            // omega order | chunk table: into a pinned slot, then ONE small kernel moves both to the device
+            int* slot = c->p_lists + (size_t)(c->p_lists_turn++ & 1u) * c->p_lists_cap;
+            std::copy(idx.begin(), idx.end(), slot);
+            std::copy(ch.begin(), ch.end(), slot + n_lane);
+            HIP_TRY(launch_stage_ints(slot, c->d_actidx, n_lane, c->d_chunks, (int)ch.size(), c->stream));
+        }
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
         c->last_fill_mode = c->tiled ? 4 : (union_walk ? 3 : 2);
         if (n_lane && c->tiled) {
@@ -749,7 +785,11 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     } else if (n_act >= c->wl_min) {
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
-        HIP_TRY(hipMemcpyAsync(c->d_actidx, idx.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, c->stream));
+        {
+            int* slot = c->p_lists + (size_t)(c->p_lists_turn++ & 1u) * c->p_lists_cap;
+            std::copy(idx.begin(), idx.end(), slot);
+            HIP_TRY(launch_stage_ints(slot, c->d_actidx, n_act, nullptr, 0, c->stream));
+        }
         c->last_fill_mode = 1;
         ScopedSpan s(c, K_ASM);
         HIP_TRY(launch_assemble_wl(L, c->d_actidx, n_act, c->stream));
@@ -896,6 +936,9 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     if (c->h_lu_items) (void)hipHostFree(c->h_lu_items);
     if (c->p_act) (void)hipHostFree(c->p_act);
     if (c->p_iv) (void)hipHostFree(c->p_iv);
+    if (c->p_w) (void)hipHostFree(c->p_w);
+    if (c->p_lists) (void)hipHostFree(c->p_lists);
+    if (c->p_deferred) (void)hipHostFree(c->p_deferred);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -988,6 +1031,40 @@ int emme_assemble_batch(emme_ctx_t* c, const double* omega, int nbatch, double* 
         set_error("quadrature depth cap hit or non-finite integral in at least one item");
         return EMME_ENUMERIC;
     }
+    return EMME_OK;
+}
+
+int emme_ctx_cache_settle(emme_ctx_t* c, const double* omega, int nbatch, int* fills_done) {
+    if (!c || !omega || nbatch < 1) return EMME_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_batch(c, nbatch);
+    if (rc) return rc;
+    rc = ensure_mats(c, nbatch, 1);
+    if (rc) return rc;
+    int fills = 0;
+    // a fill that deferred integrals makes the NEXT one cache a subtree around the interval most of
+    // them were missing; at most NODE_CACHE_MAX_SUB - 1 run-time subtrees per contour class exist, so
+    // the shape is final after at most that many growing fills plus one that finds nothing to add
+    for (int round = 0; round < 2 * NODE_CACHE_MAX_SUB + 2; ++round) {
+        const double before = c->cache_bytes_used;
+        HIP_TRY(hipMemcpyAsync(c->d_omega, omega, sizeof(double) * 2 * nbatch, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_intervals, 0, sizeof(unsigned long long) * nbatch, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * nbatch, c->stream));
+        rc = do_assemble(c, nbatch, c->d_omega, nullptr, nullptr, c->d_M, nullptr, nullptr, nullptr, nullptr, omega);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        ++fills;
+        if (round > 0 && c->cache_bytes_used == before) break;  // this fill found the shape it started with
+    }
+    if (fills_done) *fills_done = fills;
+    return EMME_OK;
+}
+
+int emme_ctx_cache_state(const emme_ctx_t* c, int* full_depth, int* subtrees, double* gib) {
+    if (!c) return EMME_EINVAL;
+    if (full_depth) *full_depth = c->cache_depth;
+    if (subtrees) *subtrees = c->cache_depth >= 0 ? c->cache_geom.nsub : 0;
+    if (gib) *gib = c->cache_bytes_used / (1024.0 * 1024.0 * 1024.0);
     return EMME_OK;
 }
 
@@ -1214,14 +1291,6 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
 
     rc = refresh_cost();
     if (rc) return rc;
-    if (n > c->p_cap) {
-        if (c->p_act) (void)hipHostFree(c->p_act);
-        if (c->p_iv) (void)hipHostFree(c->p_iv);
-        c->p_act = nullptr, c->p_iv = nullptr, c->p_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&c->p_act, sizeof(int) * n));
-        HIP_TRY(hipHostMalloc((void**)&c->p_iv, sizeof(unsigned long long) * n));
-        c->p_cap = n;
-    }
     // One stream synchronisation per Newton step: the host needs the new omegas (contour
     // classes, cache growth) before it can launch the fill.  The active flags and interval
     // counts a fill leaves behind travel to pinned memory asynchronously and are read after the
@@ -1233,6 +1302,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         for (int b = 0; b < n; ++b) {
             act[b] = c->p_act[b];
             iv_now[b] = c->p_iv[b];
+            c->last_deferred = *c->p_deferred, c->pub_valid = true;
             if (iv_now[b] != iv_prev[b]) cost[b] = iv_now[b] - iv_prev[b];
             iv_prev[b] = iv_now[b];
         }
@@ -1270,10 +1340,10 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         {
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(launch_newton_update(n, c->d_tr, c->d_omega, c->d_domega, c->d_active, c->d_iters,
-                                         c->d_info, tol, c->d_iterates, j, stride, c->stream));
+                                         c->d_info, tol, c->d_iterates, j, stride, c->stream, c->p_w));
         }
-        HIP_TRY(hipMemcpyAsync(h_w.data(), c->d_omega, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::copy(c->p_w, c->p_w + 2 * (size_t)n, h_w.begin());
         if (pending) {
             take_pending();
             bool any = false;
@@ -1285,10 +1355,9 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         if (rc) return rc;
         {
             ScopedSpan s(c, K_OTHER);
-            HIP_TRY(launch_retire(n, c->d_active, c->stream));
+            HIP_TRY(launch_retire(n, c->d_active, c->stream, c->p_act, c->d_intervals, c->p_iv,
+                                  c->d_worklist_count, c->p_deferred));
         }
-        HIP_TRY(hipMemcpyAsync(c->p_act, c->d_active, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->p_iv, c->d_intervals, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
         pending = true, j_pending = j;
     }
     std::vector<unsigned long long> iv(n);

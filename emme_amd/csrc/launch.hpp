@@ -137,10 +137,15 @@ hipError_t launch_transpose(int n, int nbatch, const double* in, double* out, co
 hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,
                                 int* active, int* iters, const int* info, double tol,
                                 double* iterates, int iter_index, int iter_stride,
-                                hipStream_t stream);
+                                hipStream_t stream, double* pub_omega = nullptr /* pinned host, all omegas */);
 
-// active == 2 ("converged, last step done") -> 0
-hipError_t launch_retire(int nbatch, int* active, hipStream_t stream);
+// active == 2 ("converged, last step done") -> 0; pub_* (pinned host, nullable): the flags, the interval
+// counters and the deferred-integral count for the host to read after its next synchronisation
+hipError_t launch_retire(int nbatch, int* active, hipStream_t stream, int* pub_active = nullptr,
+                         const unsigned long long* intervals = nullptr, unsigned long long* pub_intervals = nullptr,
+                         const unsigned int* deferred = nullptr, unsigned int* pub_deferred = nullptr);
+// small integer lists from a pinned host block to device memory: dst1 <- src[0..n1), dst2 <- src[n1..n1+n2)
+hipError_t launch_stage_ints(const int* src_pinned, int* dst1, int n1, int* dst2, int n2, hipStream_t stream);
 
 // Mp = (M - Mold) / domega, elementwise (include/solver.h:54-57), for active items.
 hipError_t launch_secant(int nbatch, size_t nn, const double* M, const double* Mold,

@@ -159,10 +159,13 @@ __global__ __launch_bounds__(LU_THREADS) void k_trace_solve(int n, double2* A, d
 
 __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, double2* domega,
                                 int* active, int* iters, const int* info, double tol,
-                                double2* iterates, int iter_index, int iter_stride) {
+                                double2* iterates, int iter_index, int iter_stride, double2* pub_omega) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbatch) return;
-    if (active && active[b] == 0) return;
+    if (active && active[b] == 0) {
+        if (pub_omega) pub_omega[b] = omega[b];
+        return;
+    }
     // d_eigen_value = -1 / trace; eigen_value += d (include/solver.h:139-140)
     const cd t = mk(tr[b].x, tr[b].y);
     const cd d = -rcp(t);
@@ -172,6 +175,9 @@ __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, d
     domega[b] = make_double2(d.x, d.y);
     if (iters) iters[b] += 1;
     if (iterates) iterates[(size_t)b * iter_stride + iter_index] = make_double2(w.x, w.y);
+    // the host needs the new omegas (contour classes) before it launches the fill: written straight
+    // into its pinned memory instead of a device-to-host copy of their own
+    if (pub_omega) pub_omega[b] = make_double2(w.x, w.y);
     if (active) {
         // stop when |d| < |tol * omega| (src/main.cpp:53-56) or on a failed factorisation.
         // The reassembly at the new omega still happens this step (solver.h:157), so the
@@ -185,9 +191,30 @@ __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, d
     }
 }
 
-__global__ void k_retire(int nbatch, int* active) {
+// active == 2 ("converged, last step done") -> 0; and what the host reads after the next step's
+// synchronisation -- the active flags, the interval counters and the number of integrals the fill
+// deferred -- goes straight into its pinned memory (one kernel instead of three small copies)
+__global__ void k_retire(int nbatch, int* active, int* pub_active, const unsigned long long* intervals,
+                         unsigned long long* pub_intervals, const unsigned int* deferred, unsigned int* pub_deferred) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbatch && active[b] == 2) active[b] = 0;
+    if (b == 0 && pub_deferred) *pub_deferred = deferred ? *deferred : 0u;
+    if (b >= nbatch) return;
+    int a = active[b];
+    if (a == 2) active[b] = a = 0;
+    if (pub_active) pub_active[b] = a;
+    if (pub_intervals) pub_intervals[b] = intervals[b];
+}
+
+// dst1[0..n1) = src[0..n1), dst2[0..n2) = src[n1..n1+n2): the small per-launch lists (omega order,
+// chunks, live matrices) go from the host's pinned staging block to device memory in one kernel
+__global__ void k_stage_ints(const int* src, int* dst1, int n1, int* dst2, int n2) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n1 + n2; k += gridDim.x * blockDim.x) {
+        const int v = src[k];
+        if (k < n1)
+            dst1[k] = v;
+        else
+            dst2[k - n1] = v;
+    }
 }
 
 __global__ void k_secant(size_t nn, const double2* M, const double2* Mold, const double2* domega,
@@ -233,15 +260,24 @@ hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int
 hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,
                                 int* active, int* iters, const int* info, double tol,
                                 double* iterates, int iter_index, int iter_stride,
-                                hipStream_t stream) {
+                                hipStream_t stream, double* pub_omega) {
     hipLaunchKernelGGL(k_newton_update, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch,
                        (const double2*)tr, (double2*)omega, (double2*)domega, active, iters, info,
-                       tol, (double2*)iterates, iter_index, iter_stride);
+                       tol, (double2*)iterates, iter_index, iter_stride, (double2*)pub_omega);
     return hipGetLastError();
 }
 
-hipError_t launch_retire(int nbatch, int* active, hipStream_t stream) {
-    hipLaunchKernelGGL(k_retire, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch, active);
+hipError_t launch_retire(int nbatch, int* active, hipStream_t stream, int* pub_active,
+                         const unsigned long long* intervals, unsigned long long* pub_intervals,
+                         const unsigned int* deferred, unsigned int* pub_deferred) {
+    hipLaunchKernelGGL(k_retire, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch, active, pub_active,
+                       intervals, pub_intervals, deferred, pub_deferred);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_ints(const int* src_pinned, int* dst1, int n1, int* dst2, int n2, hipStream_t stream) {
+    if (n1 + n2 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stage_ints, dim3((n1 + n2 + 255) / 256), dim3(256), 0, stream, src_pinned, dst1, n1, dst2, n2);
     return hipGetLastError();
 }
 

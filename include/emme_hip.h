@@ -108,6 +108,18 @@ int emme_ctx_dim(const emme_ctx_t* ctx); /* N if beta_e == 0 else 2N */
 int emme_ctx_fill_mode(const emme_ctx_t* ctx);
 /* GiB of HBM currently held by the node-record cache (0 if none). */
 double emme_ctx_node_cache_gib(const emme_ctx_t* ctx);
+/* The node cache grows at run time: a fill that had to hand integrals to the from-scratch kernel
+ * (their trees leave the cached intervals) makes the next fill cache a subtree around the interval
+ * they were missing.  An integral that moves from one kernel to the other keeps its interval count
+ * but changes its rounding (summation order, folded amplitudes: ~1e-16 relative, 1e-12 at strongly
+ * damped omega), so a root search on a fresh context and on a warm one differ at that level.  The
+ * CANONICAL state is the settled one: emme_ctx_cache_settle fills M(omega_b) for the given omegas
+ * (host, 2*nbatch doubles; results discarded) until a fill leaves the cache shape unchanged; after
+ * it, fills of omegas in the same region are bit-for-bit repeatable.  fills_done (nullable): fills run. */
+int emme_ctx_cache_settle(emme_ctx_t* ctx, const double* omega, int nbatch, int* fills_done);
+/* Shape of the cache: depth of the fully cached tree (-1 none yet, -2 disabled / does not fit),
+ * number of cached subtrees (the fixed one included), GiB held.  Any pointer may be NULL. */
+int emme_ctx_cache_state(const emme_ctx_t* ctx, int* full_depth, int* subtrees, double* gib);
 int emme_ctx_profile_enable(emme_ctx_t* ctx, int on);
 int emme_ctx_profile_read(emme_ctx_t* ctx, emme_profile_t* out, int reset);
 

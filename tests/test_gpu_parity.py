@@ -398,7 +398,8 @@ KERNEL_MODES = {
     "cached-dense": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1"},
     "cached-dense-all-sparse": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1", "EMME_DENSE_MIN_COLS": "17"},
     "cached-dense-all-mfma": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1", "EMME_DENSE_MIN_COLS": "1"},
-    "cached-dense-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_DENSE": "1"},
+    "cached-dense-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_DENSE": "1",
+                          "EMME_CACHE_MIN_DEPTH": "0"},
     # the same with the independent-lane kernel for every case
     "cached-independent": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
     # unfolded records, exp(A0 + T omega) evaluated per (pair, node, omega) in the fill
@@ -406,8 +407,9 @@ KERNEL_MODES = {
     # electromagnetic cases with one record per moment instead of the shared layout
     "cached-em-per-moment": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_EM_SHARED": "0"},
     # cache too small for anything but the shallowest tree: most integrals are deferred
-    "cached-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1"},
-    "cached-tiny-independent": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
+    "cached-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_CACHE_MIN_DEPTH": "0"},
+    "cached-tiny-independent": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_UNION": "0",
+                                "EMME_CACHE_MIN_DEPTH": "0"},
     # no cache: omega-lane kernel (node data shared on the fly inside a lane group)
     "omega-lane": {"EMME_NODE_CACHE_GB": "0", "EMME_WL_MIN": "1"},
     # no cache, lanes-are-nodes kernel only
@@ -454,8 +456,7 @@ def test_union_fill_bits_do_not_depend_on_intervals_per_round(emme, monkeypatch)
         # builds the cache and lets it grow to its final shape (a fill that deferred integrals
         # makes the next one cache a subtree around them, at most NODE_CACHE_MAX_SUB times; an
         # integral that moves from the cooperative kernel to the cached path changes its rounding)
-        for _ in range(8):
-            ctx.assemble(ws)
+        ctx.cache_settle(ws)
         monkeypatch.setenv("EMME_UNION_SEL", "1")
         M1, iv1 = ctx.assemble(ws, want_intervals=True)
         monkeypatch.setenv("EMME_UNION_SEL", "2")

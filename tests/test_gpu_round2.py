@@ -85,12 +85,24 @@ def test_cfg3_headline_shape_matches_reference_chains(emme, monkeypatch):
                             roots2=roots2, iters2=iters2, info2=info2)
     conv = done & (z["converged"] == 1)
     assert conv.sum() >= 0.7 * done.sum()
+    # Which roots can two correct fp64 implementations be asked to share to 1e-9?  Those the REFERENCE
+    # itself reproduces when its input changes in the last digit (second pass of make_golden_cfg3.py:
+    # guess * (1 + 1e-13)).  One chain of this lattice (#30) jumps to Re omega > 0, where matrix
+    # entries are ~1e57 and the remainder of integrand values 1e16 larger -- pure rounding noise in the
+    # reference too (tests/analysis/folded_probe.py) -- and ends on a "root" that moves by ~1e-7.
+    sens = np.abs(z["roots_perturbed"] - z["roots"]) / np.abs(z["roots"])
+    stable = conv & (z["done_perturbed"] == 1) & (sens <= 1e-10) & (z["iters_perturbed"] == z["iters"])
+    assert stable.sum() >= 100
     n_cmp = 0
     for b in np.nonzero(conv)[0]:
         k = int(z["iters"][b])
         assert info[b] == 0, (b, g[b], info[b])
         assert iters[b] == k, (b, g[b], iters[b], k)
         want = z["iterates"][b, :k]
+        if not stable[b]:
+            # same path as long as the reference's own path is reproducible, same verdict at the end
+            assert abs(roots[b] - z["roots"][b]) <= max(1e-9, 1e3 * sens[b]) * abs(z["roots"][b]), (b, g[b], sens[b])
+            continue
         # every iterate: chains that visit strongly damped omegas on their way amplify rounding there
         # (M is conditioned to ~1e-8 at those points), so the intermediate iterates are held
         # to 1e-6 relative and the ROOT to 1e-9
@@ -98,17 +110,23 @@ def test_cfg3_headline_shape_matches_reference_chains(emme, monkeypatch):
         assert abs(roots[b] - z["roots"][b]) <= TOL_W * abs(z["roots"][b]), (b, g[b], roots[b], z["roots"][b])
         assert abs(roots2[b] - z["roots"][b]) <= TOL_W * abs(z["roots"][b]) and iters2[b] == k
         n_cmp += 1
-    assert n_cmp >= 8
+    assert n_cmp >= 100
+    # the one chain the reference abandons (zsysv reports an exactly singular factor at step 3 from
+    # guess -1.2+0.3i: M holds infinities at omega = -0.0055-0.734i) fails here too, at the same step
+    for b in np.nonzero(done & (z["info"] != 0))[0]:
+        assert info[b] != 0 and iters[b] == z["iters"][b], (b, g[b], info[b], iters[b])
     # Chains the reference does not converge within its 21 steps wander through strongly damped
     # omegas, where a Newton step amplifies last-bit differences of M (conditioned to ~1e-8 there): no
     # late-iterate parity exists for them, in either direction.  What is pinned: the chain follows the
-    # reference's for its first steps (until the first iterate with Im omega < -0.5, at least 3 steps).
-    for b in np.nonzero(done & (z["converged"] == 0))[0]:
+    # reference's up to and including the first iterate that leaves the well-conditioned region
+    # (Re omega < -0.2, Im omega > -0.5): the step computed FROM such an omega is the first one that
+    # amplifies (near Re omega = 0 the entries grow to 1e50 and beyond, below Im omega = -0.5 to 1e38).
+    for b in np.nonzero(done & (z["converged"] == 0) & (z["info"] == 0))[0]:
         want = z["iterates"][b, :int(z["iters"][b])]
-        deep = np.nonzero(want.imag < -0.5)[0]
-        k = max(3, int(deep[0]) if deep.size else len(want) // 2)
+        rough = np.nonzero(~((want.real < -0.2) & (want.imag > -0.5)))[0]
+        k = int(rough[0]) + 1 if rough.size else len(want)
         k = min(k, int(iters[b]), len(want))
-        assert np.abs(its[b, :k] - want[:k]).max() <= 1e-6 * np.abs(want[:k]).max(), (b, g[b], k)
+        assert np.abs(its[b, :k] - want[:k]).max() <= TOL_W * np.abs(want[:k]).max(), (b, g[b], k)
 
 
 def test_run_json_marks_enumeric_failures_as_nan_records(emme):
@@ -136,3 +154,94 @@ def test_rccl_gather_through_c_abi_single_rank(emme):
     with pytest.raises(emme.EmmeError):
         comm.gather_roots(roots, [4, 5, 21], [0, 0, -6], 5)  # not this rank's share: refused before the collective
     comm.close()
+
+
+def test_cache_settle_is_the_canonical_state(emme, oracle, monkeypatch):
+    """emme_ctx_cache_settle grows the node cache to its final shape for a set of omegas; from then
+    on fills are bit-for-bit repeatable, and a second context settled the same way gives the same
+    bits (fresh-vs-warm differences exist only while the cache is still growing)."""
+    monkeypatch.setenv("EMME_NODE_CACHE_GB", "8")
+    d = example_tokamak(npoints=48)
+    ws = np.array([-0.8 + 0.25j, -0.6 - 0.21j, -0.142 - 1.469j, 0.153 - 0.316j, 4.591 - 3.987j,
+                   -0.35 - 0.788j, 0.6 + 0.1j, -0.7 + 0.3j, -0.9 + 0.1j])
+    po = oracle.params(d)
+    mats = []
+    for _ in range(2):
+        with _ctx(emme, d) as ctx:
+            depth0, sub0, gib0 = ctx.cache_state()
+            assert depth0 == -1 and gib0 == 0.0
+            fills = ctx.cache_settle(ws)
+            depth, sub, gib = ctx.cache_state()
+            assert 2 <= fills <= 14 and depth >= 3 and sub >= 1 and gib > 0.0
+            ctx.cache_settle(ws)
+            assert ctx.cache_state()[1:] == (sub, gib)  # nothing left to grow
+            M1, iv1 = ctx.assemble(ws, want_intervals=True)
+            M2, iv2 = ctx.assemble(ws, want_intervals=True)
+            assert np.array_equal(M1.view(np.float64), M2.view(np.float64), equal_nan=True) and np.array_equal(iv1, iv2)
+            mats.append(M1)
+    assert np.array_equal(mats[0].view(np.float64), mats[1].view(np.float64), equal_nan=True)
+    for k, w in enumerate(ws):
+        Mo, tot = oracle.assemble(po, complex(w))
+        assert iv1[k] == tot
+        if w.imag < -2.0:
+            continue  # entries ~1e24 that are remainders of far larger integrand values: only the tree is pinned
+        tol = 1e-6 if w.imag < -0.5 else TOL_M  # strongly damped: both sides carry ~1e-8 (DESIGN 2)
+        assert np.abs(mats[0][k] - Mo).max() <= tol * np.abs(Mo).max(), w
+
+
+# ---- BASELINE configs[3]: stellarator, electromagnetic, GK31 ----------------------------------------
+def test_stellarator_k8_fixed_work_step_by_step(emme):
+    """the reference's own chain does not converge at configs[3], so the configuration is
+    scored as FIXED WORK -- K = 8 trace-secant Newton steps per guess -- compared step by step with
+    chains computed from the reference's kappa sources + LAPACK zsysv (make_golden_stellarator.py),
+    for guesses on both sides of Im omega = 0 (13x deeper trees below)."""
+    z = np.load(os.path.join(G, "stellarator_k8.npz"))
+    for n in (32, 48):
+        g, want = z[f"n{n}_guesses"], z[f"n{n}_iterates"]
+        with _ctx(emme, example_stellarator(npoints=n)) as ctx:
+            roots, iters, info, its = ctx.solve_roots(g, tol=0.0, step_limit=7, want_iterates=True)
+        assert (iters == 8).all() and (info == 0).all()
+        for b in range(len(g)):
+            err = np.abs(its[b, :8] - want[b]) / np.abs(want[b])
+            # loose quadrature goal (1e-2) makes M only piecewise smooth; steps are compared to 1e-8
+            assert err.max() <= 1e-8, (n, g[b], err)
+
+
+def test_stellarator_full_size_assembly_against_reference_checksums(emme):
+    """N=256 (dim 512) electromagnetic matrices at the shipped guess and at a damped omega against
+    checksums of the reference's own kappa sources: every block, sampled entries, row sums."""
+    chk = json.load(open(os.path.join(G, "matrix_checksums_stellarator.json")))
+    d = example_stellarator(npoints=256)
+    ws = np.array([complex(*chk[t]["omega"]) for t in ("guess", "damped")])
+    with _ctx(emme, d) as ctx:
+        M = ctx.assemble(ws)
+    for k, t in enumerate(("guess", "damped")):
+        c = chk[t]
+        scale = c["max_abs"]
+        assert abs(np.linalg.norm(M[k]) - c["fro"]) <= 1e-10 * c["fro"]
+        blocks = {"A": M[k][:256, :256], "B": M[k][:256, 256:], "C": M[k][256:, :256], "D": M[k][256:, 256:]}
+        for name, blk in blocks.items():
+            assert abs(blk.sum() - complex(*c["block_sums"][name])) <= 1e-9 * scale * 256, (t, name)
+        for i, j, re, im in c["entries"]:
+            assert abs(M[k][int(i), int(j)] - complex(re, im)) <= TOL_M * scale, (t, i, j)
+        rows = np.abs(M[k]).sum(axis=1)
+        assert np.allclose(rows[:8], c["row_abs_sums_first8"], rtol=1e-10, atol=0)
+        assert np.allclose(rows[-8:], c["row_abs_sums_last8"], rtol=1e-10, atol=0)
+
+
+# ---- BASELINE configs[4]: the 512-point grid ----------------------------------------------------------
+def test_n512_full_size_assembly_against_reference_checksums(emme):
+    """N=512 electrostatic matrices at two k_rho values of the sweep (omegas on both sides of
+    Im omega = 0) against checksums of the reference's own kappa sources."""
+    import bench
+    chk = json.load(open(os.path.join(G, "matrix_checksums_n512.json")))
+    for tag, c in chk.items():
+        w = complex(*c["omega"])
+        with _ctx(emme, bench.workload_dict(512, k_rho=c["k_rho"], omega_d_coeff=1.01)) as ctx:
+            M = ctx.assemble([w])[0]
+        scale = c["max_abs"]
+        assert abs(np.linalg.norm(M) - c["fro"]) <= 1e-10 * c["fro"], tag
+        assert abs(M.sum() - complex(*c["sum"])) <= 1e-9 * scale * 512, tag
+        for i, j, re, im in c["entries"]:
+            assert abs(M[int(i), int(j)] - complex(re, im)) <= TOL_M * scale, (tag, i, j)
+        assert np.allclose(np.abs(M).sum(axis=1)[:8], c["row_abs_sums_first8"], rtol=1e-10, atol=0)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the assembly kernel alone (development tool, run on the GPU box):
-  python tools/asm_bench.py [--n 256] [--batch 32] [--reps 3] [--check]
-Prints ms per matrix, integrand evaluations/s and the fp64-vector fraction; --check compares
-a small case against the oracle first (parity guard while optimising)."""
+  python tools/asm_bench.py [--n 256] [--batch 32] [--reps 3] [--stell]
+Prints ms per matrix, integrand evaluations/s and the fp64-vector fraction (parity is the tests' job:
+python -m pytest tests -m gpu)."""
 import argparse
 import os
 import sys
@@ -20,26 +20,11 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--check", action="store_true")
     ap.add_argument("--stell", action="store_true")
     a = ap.parse_args()
     import torch
-    if a.check:
-        from oracle.binding import Oracle, example_stellarator, example_tokamak
-        orc = Oracle()
-        for d, ws in [(example_tokamak(npoints=48), [-0.8 + 0.25j, -0.6 - 0.21j, 0.5 + 0.1j]),
-                      (example_stellarator(npoints=10), [-1.656 + 2.49j, -0.85 - 0.32j])]:
-            po = orc.params(d)
-            with emme_amd.Context(emme_amd.params_from_dict(d)) as ctx:
-                M, iv = ctx.assemble(ws, want_intervals=True)
-            for k, w in enumerate(ws):
-                Mo, tot = orc.assemble(po, w)
-                err = np.abs(M[k] - Mo).max() / np.abs(Mo).max()
-                print(f"check {d['conf']} w={w}: rel err {err:.2e} intervals {iv[k]} vs {tot}")
-                assert err < 1e-10 and iv[k] == tot
     if a.stell:
-        from oracle.binding import example_stellarator
-        d = example_stellarator(npoints=a.n)
+        d = dict(bench.STELLARATOR, npoints=a.n)
         g = np.linspace(-1.8, -1.4, a.batch) + 1j * np.linspace(2.2, 2.7, a.batch)
     else:
         d = bench.workload_dict(a.n)

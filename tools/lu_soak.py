@@ -5,9 +5,9 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import emme_amd
-from oracle.binding import example_tokamak
+import bench
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-ctx = emme_amd.Context(emme_amd.params_from_dict(example_tokamak(npoints=16)))
+ctx = emme_amd.Context(emme_amd.params_from_dict(bench.workload_dict(16)))
 rng = np.random.default_rng(2024)
 bad = 0
 total = 0

@@ -14,7 +14,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import emme_amd  # noqa: E402
-from oracle.binding import example_stellarator, example_tokamak  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -30,7 +29,7 @@ def main():
     sv = json.load(open(os.path.join(G, "survey_appendix_b.json")))
     out = []
     # configs[0]: 64-point grid, single guess (CPU plumbing case in the reference) -- on the GPU
-    with emme_amd.Context(emme_amd.params_from_dict(example_tokamak(npoints=64))) as ctx:
+    with emme_amd.Context(emme_amd.params_from_dict(bench.workload_dict(64))) as ctx:
         roots, iters, info, dt = timed_solve(ctx, [-0.8 + 0.25j])
         want = complex(-0.67067782097052198, 0.27077138768282322)  # SURVEY App. B (complete reference)
         out.append({"config": 0, "what": "N=64, one root", "seconds": dt, "root_err_vs_reference": abs(roots[0] - want),
@@ -48,7 +47,7 @@ def main():
                     "converged": int((info == 0).sum()), "chains": len(g)})
     # configs[3]: stellarator EM, N=256 (dim 512), 32x32 lattice around (-1.656, 2.490): one GPU's 128
     # guesses of the round-robin deal, fixed work K = 8 Newton steps per guess
-    d = example_stellarator(npoints=256)
+    d = dict(bench.STELLARATOR, npoints=256)
     re, im = np.linspace(-1.756, -1.556, 32), np.linspace(2.39, 2.59, 32)
     lat = (re[None, :] + 1j * im[:, None]).reshape(-1)[0::8]
     with emme_amd.Context(emme_amd.params_from_dict(d)) as ctx:
@@ -62,7 +61,7 @@ def main():
     guesses = guesses.reshape(-1)
     t_all, pts, conv = 0.0, 0, 0
     for kr in krs:
-        with emme_amd.Context(emme_amd.params_from_dict(example_tokamak(npoints=512, k_rho=float(kr)))) as ctx:
+        with emme_amd.Context(emme_amd.params_from_dict(bench.workload_dict(512, k_rho=float(kr)))) as ctx:
             roots, iters, info, dt = timed_solve(ctx, guesses)
             t_all += dt
             pts += int(iters.sum())

@@ -3,11 +3,10 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import emme_amd
-from oracle.binding import example_stellarator
+import bench, emme_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-d = example_stellarator(npoints=n, iteration_step_limit=30)
+d = dict(bench.STELLARATOR, npoints=n, iteration_step_limit=30)
 p = emme_amd.params_from_dict(d)
 g = (np.linspace(-1.8, -1.5, nb) + 1j * np.linspace(2.3, 2.6, nb))
 ctx = emme_amd.Context(p)
