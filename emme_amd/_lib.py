@@ -315,7 +315,7 @@ class Context:
     FILL_KERNELS = {0: "k_assemble (lanes=nodes)", 1: "k_assemble_wl (omega-lane)",
                     2: "k_assemble_cached (HBM node cache)",
                     3: "k_assemble_union (HBM node cache + phase table)",
-                    4: "k_assemble_dense (tiled HBM node cache, FP64 matrix cores)"}
+                    4: "k_assemble_dense (tiled HBM node cache + weighted phase tables, FP64 matrix cores)"}
 
     def fill_kernel(self) -> str:
         return self.FILL_KERNELS.get(self.lib.emme_ctx_fill_mode(self.h), "none yet")

@@ -77,8 +77,9 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
             which < 0 ? tb + ((size_t)tile * A.geom.ni_main() + cslot) * TILE_BLOCK
                       : tb + ((size_t)tile * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * TILE_BLOCK;
         const int sn = slotnode_of_lane(lane_in_group);
-        const cd q1 = mk(blk[(2 * sn) * 16 + p], blk[512 + (2 * sn) * 16 + p]);
-        const cd q0 = mk(blk[(2 * sn + 1) * 16 + p], blk[512 + (2 * sn + 1) * 16 + p]);
+        const double2* q = reinterpret_cast<const double2*>(blk);
+        const double2 r1 = q[(2 * sn) * 16 + p], r0 = q[(2 * sn + 1) * 16 + p];
+        const cd q1 = mk(r1.x, r1.y), q0 = mk(r0.x, r0.y);
         const double rea0 = blk[1024 + lane_in_group * 16 + p];
         const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
         const cd arg = mk(tt.x, tt.y) * oc.omega;

@@ -11,7 +11,7 @@
 // (include/solver.h:446-455 fills them one task each) and walks the UNION of their adaptive trees in
 // pre-order, one interval per round:
 //   dense round  (the interval is in the trees of >= 3 omega columns): 48 v_mfma_f64_16x16x4_f64 --
-//                 32 for K (k = 32), 16 for G (k = 16) -- fed by 40 coalesced 512-byte loads, no
+//                 32 for K (k = 32), 16 for G (k = 16) -- fed by 20 coalesced 1-KB loads, no
 //                 per-element address or key arithmetic at all;
 //   sparse round (1-2 columns: a chain that has wandered to a damped omega refines where nobody
 //                 else does): lane = node, DPP row sums, 16 pairs of one omega at a time;
@@ -119,10 +119,9 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
                 if (lane == 0) A.scale[A.first + idx] = scale;
             }
         }
-        blk[(2 * sn) * 16 + p] = q1.x;
-        blk[512 + (2 * sn) * 16 + p] = q1.y;
-        blk[(2 * sn + 1) * 16 + p] = q0.x;
-        blk[512 + (2 * sn + 1) * 16 + p] = q0.y;
+        double2* q = reinterpret_cast<double2*>(blk);
+        q[(2 * sn) * 16 + p] = make_double2(q1.x, q1.y);
+        q[(2 * sn + 1) * 16 + p] = make_double2(q0.x, q0.y);
         blk[1024 + lane * 16 + p] = rea0;
     }
 }
@@ -132,6 +131,7 @@ struct BtabArgs {
     const double2* ttab[2];
     const double2* omega;
     const int* act_idx;
+    const int* wmap;  // per position of the launch's omega list: chunk << 8 | column
     int n_act, nchunks, nslots;
     double* btab;
 };
@@ -160,17 +160,16 @@ __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
         const GkLane gk = gk_lane<15>(lane);
         const int sn = slotnode_of_lane(lane);
         const cd we = mk(om.x, om.y) * ev;
-        double* blk = A.btab + ((size_t)slot * A.nchunks + (wpos >> 4)) * BTAB_BLOCK;
-        const int col = wpos & 15;
-        blk[(2 * sn) * 16 + col] = gk.wk * we.x;
-        blk[512 + (2 * sn) * 16 + col] = gk.wk * we.y;
-        blk[(2 * sn + 1) * 16 + col] = gk.wk * ev.x;
-        blk[512 + (2 * sn + 1) * 16 + col] = gk.wk * ev.y;
+        const int wm = A.wmap[wpos];
+        double* blk = A.btab + ((size_t)slot * A.nchunks + (wm >> 8)) * BTAB_BLOCK;
+        const int col = wm & 255;
+        double2* bk = reinterpret_cast<double2*>(blk);
+        bk[(2 * sn) * 16 + col] = make_double2(gk.wk * we.x, gk.wk * we.y);
+        bk[(2 * sn + 1) * 16 + col] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
         if (sn < 8) {  // rows 0..15 of the Gauss table (sn 7 is a Kronrod-only node: wg = 0)
-            blk[1024 + (2 * sn) * 16 + col] = gk.wg * we.x;
-            blk[1280 + (2 * sn) * 16 + col] = gk.wg * we.y;
-            blk[1024 + (2 * sn + 1) * 16 + col] = gk.wg * ev.x;
-            blk[1280 + (2 * sn + 1) * 16 + col] = gk.wg * ev.y;
+            double2* bg = bk + 512;
+            bg[(2 * sn) * 16 + col] = make_double2(gk.wg * we.x, gk.wg * we.y);
+            bg[(2 * sn + 1) * 16 + col] = make_double2(gk.wg * ev.x, gk.wg * ev.y);
         }
     }
 }
@@ -188,6 +187,7 @@ struct DenseArgs {
     unsigned long long* defer_info;
     unsigned int* worklist_count;
     const int* act_idx;
+    const int2* chunks;  // (first position, size <= 16) of every omega chunk
     int n_act, nchunks;
     const double2* omega;
     double2* M;
@@ -200,268 +200,294 @@ struct DenseArgs {
     int dense_min_cols;         // columns that must need an interval for the MFMA path
 };
 
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long x) {
-    const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    return o < x ? o : x;
-}
-// minimum over the whole wave, as a wave-uniform (scalar) value
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-    v = dpp_min_u64<0xB1>(v);
-    v = dpp_min_u64<0x4E>(v);
-    v = dpp_min_u64<0x141>(v);
-    v = dpp_min_u64<0x140>(v);
-    unsigned long long m = ~0ull;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * r);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * r);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        m = o < m ? o : m;
-    }
-    return m;
+// ---- the fill: level by level ----------------------------------------------------------------------
+// (A first version walked the union tree in pre-order like k_assemble_union, one interval per round
+// chosen by a wave-wide key minimum: every round was a chain of exposed latencies and the tasks of the
+// expensive omega chunk, interleaved with the others, finished last: 128 ms per bench search against 66
+// for this form.)  The 256 integrals of a wave advance one bisection LEVEL at a time: the intervals of the current level that
+// any element needs form a list of at most 64 entries (entry e lives in lane e of a register pair, read
+// with v_readlane), every element holds a 64-bit mask of the entries it needs, and an entry that some
+// element splits appends its two children to the next level's list.  Entries of a level are independent
+// of each other, there is no key arithmetic and no minimum search, and the accepted pieces are added
+// level by level instead of left to right (a rounding-level change, like the cooperative kernel's).
+// An element whose split does not fit the next list (more than 64 intervals of one level in a tile:
+// not met in the tests or the bench) is handed, whole, to the cooperative kernel.
+__device__ __forceinline__ double fsqrt_pos(double x) {
+    // sqrt for the error estimates: hardware reciprocal-square-root seed + two Newton steps (<= 1 ulp
+    // for normal arguments), 0 for 0 and NaN for NaN
+    const double y = x * frsqrt(x);
+    return x > 0.0 ? y : x;
 }
 
 #ifndef EMME_DENSE_MIN_WAVES
-#define EMME_DENSE_MIN_WAVES 2
+#define EMME_DENSE_MIN_WAVES 3
 #endif
 
 __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(DenseArgs A) {
-    constexpr int KD = 56;
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, rho = lane >> 4;
-    // XCD-aware task order: consecutive blocks go round-robin over the 8 XCDs (block L and L + 8
-    // share one), so the chunk index cycles fastest WITHIN an XCD: the waves that read a tile's
-    // records for its different omega chunks run on one XCD at about the same time and share its L2
+    // task order: the chunks of the cost-sorted omega list hold the most expensive omegas first, and
+    // their tasks are the longest: chunk-major, so that they all start at once and the cheap ones fill in
     const int ntiles = (A.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;  // tile groups: 4 tiles (one per wave) per workgroup
-    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
-    const int chunk = q % A.nchunks;
-    const int tg = (q / A.nchunks) * 8 + xcd;
-    if (tg >= ntg) return;
-    const int tile = tg * 4 + wave;
+    const int chunk = blockIdx.x / ntg;
+    const int tile = (blockIdx.x - chunk * ntg) * 4 + wave;
     if (tile >= ntiles) return;
 
-    const int n_in_chunk = min(16, A.n_act - 16 * chunk);
-    const bool has_w = col < n_in_chunk;
-    const int wpos = 16 * chunk + (has_w ? col : 0);
+    const int2 ch = A.chunks[chunk];
+    const bool has_w = col < ch.y;
+    const int wpos = ch.x + (has_w ? col : 0);
     const int b = A.act_idx[wpos];
-    cd omega = mk(A.omega[b].x, A.omega[b].y), rdw = mk(0.0, 0.0);
-    if (A.Mold) rdw = rcp(mk(A.domega[b].x, A.domega[b].y));
-    const unsigned long long cls = -copysign(1.0, omega.x) > 0.0 ? 0ull : 1ull;
-    double2* Mb = A.M + (size_t)b * dim * dim;
-    const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
-    double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
-    auto store = [&](int r, int c, cd v) {
-        const size_t idx = (size_t)r * dim + c;
-        Mb[idx] = make_double2(v.x, v.y);
-        if (Moldb) {
-            const double2 o = Moldb[idx];
+    const int cls = -copysign(1.0, A.omega[b].x) > 0.0 ? 0 : 1;
+    // (everything the stores need is fetched again after the walk: nothing of it stays live in the loop)
+    auto store = [&](int r, int c, cd v, cd rdw) {
+        const size_t idx = (size_t)b * dim * dim + (size_t)r * dim + c;
+        A.M[idx] = make_double2(v.x, v.y);
+        if (A.Mold) {
+            const double2 o = A.Mold[idx];
             const cd d = (v - mk(o.x, o.y)) * rdw;
-            Mpb[idx] = make_double2(d.x, d.y);
+            A.Mp[idx] = make_double2(d.x, d.y);
         }
     };
-    if (tile == 0 && has_w)  // diagonal (include/solver.h:442-443)
-        for (int i = rho; i < N; i += 4) store(i, i, mk(P.diag_a, 0.0));
+    if (tile == 0 && has_w) {  // diagonal (include/solver.h:442-443)
+        const cd rdw0 = A.Mold ? rcp(mk(A.domega[b].x, A.domega[b].y)) : mk(0.0, 0.0);
+        for (int i = rho; i < N; i += 4) store(i, i, mk(P.diag_a, 0.0), rdw0);
+    }
 
     const double inv_scale = 2. / (M_PI / 2.0);
-    const unsigned long long DONE = ~0ull;
-    auto make_key = [](int depth, unsigned long long path) -> unsigned long long {
-        return ((path << (KD - depth)) << 6) | (unsigned long long)depth;
-    };
-
     // ---- the wave's 256 integrals: element r of this lane = (pair tile*16 + rho + 4 r, omega col) -----
-    unsigned long long key[4];
-    double abs_tol[4];
-    cd sum[4];
-    int count[4];
-    bool deferred[4];
+    unsigned long long mcur[4], mnext[4];  // entries of the current / next level this element needs
+    // per-element accumulators live in LDS (touched only by their owner lane, only when the element owns
+    // the entry): 28 VGPRs less per lane, which is what lets a third wave onto the SIMD
+    __shared__ double s_sumx[4][4][64], s_sumy[4][4][64], s_abstol[4][4][64];
+    __shared__ int s_count[4][4][64];
+    bool deferred[4], alive[4];
+    // level lists: entry e of a level = (contour class << 62 | path) in lane e of (E_lo, E_hi)
+    unsigned int ecur_lo = 0, ecur_hi = 0, enext_lo = 0, enext_hi = 0;
+    int n_cur = 0;
+    {
+        // level 0: the root interval, once per contour class present among this chunk's omegas
+        const unsigned long long c0 = __ballot(has_w && cls == 0), c1 = __ballot(has_w && cls == 1);
+        int e_of_cls[2] = {-1, -1};
+        if (c0) e_of_cls[0] = n_cur++;
+        if (c1) e_of_cls[1] = n_cur++;
+        if (c1) {
+            ecur_hi = lane == e_of_cls[1] ? (1u << 30) : ecur_hi;
+        }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int pidx = tile * TILE_PAIRS + rho + 4 * r;
-        key[r] = (has_w && pidx < A.npairs) ? (cls << 63) : DONE;  // root: depth 0, path 0
-        abs_tol[r] = 0.0, sum[r] = mk(0.0, 0.0), count[r] = 0, deferred[r] = false;
+        for (int r = 0; r < 4; ++r) {
+            const int pidx = tile * TILE_PAIRS + rho + 4 * r;
+            alive[r] = has_w && pidx < A.npairs;
+            mcur[r] = alive[r] ? (1ull << e_of_cls[cls]) : 0ull;
+            mnext[r] = 0ull;
+            s_abstol[wave][r][lane] = 0.0, s_sumx[wave][r][lane] = 0.0, s_sumy[wave][r][lane] = 0.0;
+            s_count[wave][r][lane] = 0, deferred[r] = false;
+        }
     }
     unsigned int n_dense = 0, n_sparse = 0, n_cols = 0;
     int bad = 0;
-#ifdef EMME_DENSE_STAMPS  // diagnostic build: where a round spends its cycles (never in the product build)
+#ifdef EMME_DENSE_STAMPS  // diagnostic build: where an entry spends its cycles (never in the product build)
     unsigned long long cyc_sel = 0, cyc_dense = 0, cyc_sparse = 0, cyc_dec = 0;
     const unsigned long long t_task = __builtin_amdgcn_s_memtime();
 #define STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(v)
 #endif
+    auto defer = [&](int r, int depth, int ccls, unsigned long long path) {
+        const unsigned int slot = atomicAdd(A.worklist_count, 1u);
+        A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)(tile * TILE_PAIRS + rho + 4 * r);
+        A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)ccls << 55) | (path & 0x7fffffffffffffull);
+        deferred[r] = true, alive[r] = false, mcur[r] = 0ull, mnext[r] = 0ull;
+    };
 
-    for (;;) {
-        STAMP(ts0);
-        unsigned long long mine = key[0] < key[1] ? key[0] : key[1];
-        const unsigned long long m23 = key[2] < key[3] ? key[2] : key[3];
-        mine = m23 < mine ? m23 : mine;
-        const unsigned long long cur = wave_min_u64(mine);  // wave-uniform: lives in scalar registers
-        if (cur == DONE) break;
-        const int ccls = (int)(cur >> 63);
-        const unsigned long long ck = cur & ~(1ull << 63);
-        const int depth = (int)(ck & 63ull);
-        const unsigned long long path = (ck >> 6) >> (KD - depth);
-        bool match[4];
+    for (int depth = 0; n_cur > 0; ++depth) {
+        int n_next = 0;
+        for (int e = 0; e < n_cur; ++e) {
+            STAMP(ts0);
+            const unsigned int elo = (unsigned)__builtin_amdgcn_readlane((int)ecur_lo, e);
+            const unsigned int ehi = (unsigned)__builtin_amdgcn_readlane((int)ecur_hi, e);
+            const int ccls = (int)(ehi >> 30);
+            const unsigned long long path = (((unsigned long long)(ehi & 0x3fffffffu)) << 32) | elo;
+            bool match[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) match[r] = key[r] == cur;
-        int which;
-        const int cslot = A.geom.slot(depth, path, which);
-        const double* ebuf = which >= 0 ? A.recs_ext[ccls][which] : A.recs[ccls];
-        if (cslot < 0 || ebuf == nullptr) {
-            // outside the cache: the integrals that need this interval go, whole, to the cooperative kernel
+            for (int r = 0; r < 4; ++r) match[r] = ((mcur[r] >> e) & 1ull) != 0ull;
+            const unsigned long long need = __ballot(match[0] || match[1] || match[2] || match[3]);
+            if (need == 0ull) continue;  // (its owners were deferred meanwhile)
+            int which;
+            const int cslot = A.geom.slot(depth, path, which);
+            const double* ebuf = which >= 0 ? A.recs_ext[ccls][which] : A.recs[ccls];
+            if (cslot < 0 || ebuf == nullptr) {
+                // outside the cache: the integrals that need this interval go, whole, to the cooperative kernel
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (match[r]) {
-                    const unsigned int slot = atomicAdd(A.worklist_count, 1u);
-                    A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)(tile * TILE_PAIRS + rho + 4 * r);
-                    A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)ccls << 55) |
-                                         (path & 0x7fffffffffffffull);
-                    deferred[r] = true;
-                    key[r] = DONE;
+                for (int r = 0; r < 4; ++r)
+                    if (match[r]) defer(r, depth, ccls, path);
+                continue;
+            }
+            const double* ablk =
+                which < 0 ? ebuf + ((size_t)tile * A.geom.ni_main() + cslot) * TILE_BLOCK
+                          : ebuf + ((size_t)tile * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * TILE_BLOCK;
+            const double* bblk = A.btab + ((size_t)cslot * A.nchunks + chunk) * BTAB_BLOCK;
+            const double2* a2 = reinterpret_cast<const double2*>(ablk);
+            const double2* b2 = reinterpret_cast<const double2*>(bblk);
+            unsigned int colmask = (unsigned int)((need | (need >> 16) | (need >> 32) | (need >> 48)) & 0xffffull);
+            v4d Kre = {0.0, 0.0, 0.0, 0.0}, Kim = Kre, Gre = Kre, Gim = Kre;
+            const bool dense_round = __popc(colmask) >= A.dense_min_cols;
+            STAMP(ts1);
+            if (dense_round) {
+                ++n_dense;
+                // k-steps 0..3 feed K and G (the embedded Gauss rule lives in rows 0..15), 4..7 only K; all 20
+                // operand loads are issued before the first MFMA (one exposed latency per entry, not four)
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) {
+#pragma unroll
+                    for (int ks = 2 * kp; ks < 2 * kp + 2; ++ks) {
+                        // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[k * 16 + p], B[k][w] = b2[k * 16 + w]:
+                        // both are base + 64 ks + lane in (re, im) pairs -- ONE coalesced 1-KB load each
+                        const double2 a = a2[64 * ks + lane], bk = b2[64 * ks + lane];
+                        Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
+                        Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
+                        Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, Kre, 0, 0, 0);
+                        Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, Kim, 0, 0, 0);
+                        if (ks < 4) {
+                            const double2 bg = b2[512 + 64 * ks + lane];
+                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bg.x, Gre, 0, 0, 0);
+                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bg.y, Gim, 0, 0, 0);
+                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bg.y, Gre, 0, 0, 0);
+                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bg.x, Gim, 0, 0, 0);
+                        }
+                    }
                 }
             }
-            continue;
-        }
-        const double* ablk =
-            which < 0 ? ebuf + ((size_t)tile * A.geom.ni_main() + cslot) * TILE_BLOCK
-                      : ebuf + ((size_t)tile * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * TILE_BLOCK;
-        const double* bblk = A.btab + ((size_t)cslot * A.nchunks + chunk) * BTAB_BLOCK;
-        // which omega columns own this interval
-        const unsigned long long need = __ballot(match[0] || match[1] || match[2] || match[3]);
-        unsigned int colmask = (unsigned int)((need | (need >> 16) | (need >> 32) | (need >> 48)) & 0xffffull);
-        v4d Kre = {0.0, 0.0, 0.0, 0.0}, Kim = Kre, Gre = Kre, Gim = Kre;
-        STAMP(ts1);
-        const bool dense_round = __popc(colmask) >= A.dense_min_cols;
-        if (dense_round) {
-            // ---- dense round: K = Q BK (k = 32), G = Q[:, 0:16] BG on the matrix cores ----------------
-            // operand maps (one f64 per lane): A[p = lane & 15][k = 4 ks + (lane >> 4)] = ablk[k * 16 + p],
-            // B[k][w = lane & 15] = bblk[k * 16 + w]: both are base + 64 ks + lane, 512 contiguous bytes
-            ++n_dense;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const double are = ablk[64 * ks + lane], aim = ablk[512 + 64 * ks + lane];
-                const double bre = bblk[64 * ks + lane], bim = bblk[512 + 64 * ks + lane];
-                Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(are, bre, Kre, 0, 0, 0);
-                Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(are, bim, Kim, 0, 0, 0);
-                Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, -bim, Kre, 0, 0, 0);
-                Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, bre, Kim, 0, 0, 0);
-                if (ks < 4) {
-                    const double gre = bblk[1024 + 64 * ks + lane], gim = bblk[1280 + 64 * ks + lane];
-                    Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(are, gre, Gre, 0, 0, 0);
-                    Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(are, gim, Gim, 0, 0, 0);
-                    Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, -gim, Gre, 0, 0, 0);
-                    Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, gre, Gim, 0, 0, 0);
-                }
-            }
-        } else {
-            // ---- sparse round: lane = node (sn = lane & 15), row rho takes pair rho + 4 r; one omega
-            // column at a time, 16-lane DPP row sums; the sums land in the owner lane of each element
-            ++n_sparse;
-            const int sn = col;
-            cd q1[4], q0[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = rho + 4 * r;
-                q1[r] = mk(ablk[(2 * sn) * 16 + p], ablk[512 + (2 * sn) * 16 + p]);
-                q0[r] = mk(ablk[(2 * sn + 1) * 16 + p], ablk[512 + (2 * sn + 1) * 16 + p]);
-            }
-            while (colmask) {
-                const int c = __builtin_ctz(colmask);
-                colmask &= colmask - 1;
-                ++n_cols;
-                const cd bk1 = mk(bblk[(2 * sn) * 16 + c], bblk[512 + (2 * sn) * 16 + c]);
-                const cd bk0 = mk(bblk[(2 * sn + 1) * 16 + c], bblk[512 + (2 * sn + 1) * 16 + c]);
-                cd bg1 = mk(0.0, 0.0), bg0 = mk(0.0, 0.0);
-                if (sn < 8) {
-                    bg1 = mk(bblk[1024 + (2 * sn) * 16 + c], bblk[1280 + (2 * sn) * 16 + c]);
-                    bg0 = mk(bblk[1024 + (2 * sn + 1) * 16 + c], bblk[1280 + (2 * sn + 1) * 16 + c]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const cd fk = q1[r] * bk1 + q0[r] * bk0;
-                    const cd fg = q1[r] * bg1 + q0[r] * bg0;
-                    const double kx = row16_sum(fk.x), ky = row16_sum(fk.y);
-                    const double gx = row16_sum(fg.x), gy = row16_sum(fg.y);
-                    if (col == c) Kre[r] = kx, Kim[r] = ky, Gre[r] = gx, Gim[r] = gy;
-                }
-            }
-        }
-#ifdef EMME_DENSE_STAMPS
-        // (make the stamp wait for the sums: a dependent scalar read of one accumulator lane)
-        const double probe = Kre[0] + Gim[3];
-        int stamp_dep;
-        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(stamp_dep) : "v"(__double2loint(probe)));
-#endif
-        STAMP(ts2);
-        // ---- every element that owns the interval decides for itself (include/functions.h:203-208,
-        // 231-247); depth, path and the half-width are wave-uniform, so both possible next keys are too
-        const double scale = A.scale[cslot];
-        const unsigned long long key_split = make_key(depth + 1, path << 1) | ((unsigned long long)ccls << 63);
-        unsigned long long p2 = path + 1;
-        const int tz = min(depth, (int)__builtin_ctzll(p2 | (1ull << 63)));
-        p2 >>= tz;
-        const int d2 = depth - tz;
-        const unsigned long long key_next = d2 == 0 ? DONE : (make_key(d2, p2) | ((unsigned long long)ccls << 63));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (__ballot(match[r]) == 0ull) continue;  // wave-uniform
-            if (match[r]) {
-                ++count[r];
-                const double kx = Kre[r], ky = Kim[r];
-                const double dKx = kx - Gre[r], dKy = ky - Gim[r];
-                const double absK = sqrt(fma(kx, kx, ky * ky));
-                double err = fmax(sqrt(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
+            // ---- every element that owns the interval decides for itself (include/functions.h:203-208,
+            // 231-247); an entry somebody splits puts its two children on the next level's list
+            const double scale = A.scale[cslot];
+            bool split[4] = {false, false, false, false};
+            // one decision: sums (kx, ky) / (gx, gy) of the element whose accumulators are slot [r][owner]
+            auto decide = [&](int r, int owner, double kx, double ky, double gx, double gy, int& flag_bad) -> bool {
+                const int cnt = s_count[wave][r][owner] + 1;
+                s_count[wave][r][owner] = cnt;
+                const double dKx = kx - gx, dKy = ky - gy;
+                const double absK = fsqrt_pos(fma(kx, kx, ky * ky));
+                double err = fmax(fsqrt_pos(fma(dKx, dKx, dKy * dKy)), absK * (2.0 * 2.220446049250313e-16));
                 err *= scale;
                 const double rel_abs = P.rel_tol * (absK * scale);
-                if (abs_tol[r] == 0.0) abs_tol[r] = rel_abs;
-                bool split = depth < P.max_sub && err > abs_tol[r] * inv_scale + P.prec_goal &&
-                             err > rel_abs + P.prec_goal;
-                if (split && (depth >= EMME_MAX_DEPTH || count[r] >= EMME_MAX_INTERVALS)) {
-                    split = false;
-                    bad = 1;
+                double at = s_abstol[wave][r][owner];
+                if (at == 0.0) {
+                    at = rel_abs;
+                    s_abstol[wave][r][owner] = at;
                 }
-                if (split) {
-                    key[r] = key_split;
-                } else {
-                    sum[r] = sum[r] + mk(kx * scale, ky * scale);
-                    key[r] = key_next;
+                bool sp = depth < P.max_sub && err > at * inv_scale + P.prec_goal && err > rel_abs + P.prec_goal;
+                if (sp && (depth >= EMME_MAX_DEPTH || cnt >= EMME_MAX_INTERVALS)) {
+                    sp = false;
+                    flag_bad = 1;
+                }
+                if (!sp) {
+                    s_sumx[wave][r][owner] += kx * scale;
+                    s_sumy[wave][r][owner] += ky * scale;
+                }
+                return sp;
+            };
+#ifdef EMME_DENSE_STAMPS
+            if (dense_round) {  // (make the stamp wait for the sums)
+                int dep;
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep) : "v"(__double2loint(Kre[0] + Gim[3])));
+            }
+#endif
+            STAMP(ts2);
+            if (!dense_round) {
+                // ---- vector round (one or two omega columns own the interval: a chain that wandered to a
+                // damped omega refines where nobody else does): lane = node (sn = lane & 15), row rho takes
+                // pair rho + 4 r; one omega column at a time, 16-lane DPP row sums; the sums land in the
+                // owner lane of each element.  (A lane = pair form with the decisions taken by 16 lanes on
+                // the LDS accumulators needs a third of the instructions and was 40 % SLOWER: one dependent
+                // chain per column -- loads, shuffles through LDS, square roots -- instead of four.)
+                ++n_sparse;
+                const int sn = col;
+                while (colmask) {
+                    const int c = __builtin_ctz(colmask);
+                    colmask &= colmask - 1;
+                    ++n_cols;
+                    const double2 k1 = b2[(2 * sn) * 16 + c], k0 = b2[(2 * sn + 1) * 16 + c];
+                    const cd bk1 = mk(k1.x, k1.y), bk0 = mk(k0.x, k0.y);
+                    cd bg1 = mk(0.0, 0.0), bg0 = mk(0.0, 0.0);
+                    if (sn < 8) {
+                        const double2 g1 = b2[512 + (2 * sn) * 16 + c], g0 = b2[512 + (2 * sn + 1) * 16 + c];
+                        bg1 = mk(g1.x, g1.y), bg0 = mk(g0.x, g0.y);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p = rho + 4 * r;  // (re-read per column from L1: a vector round rarely has two)
+                        const double2 r1 = a2[(2 * sn) * 16 + p], r0 = a2[(2 * sn + 1) * 16 + p];
+                        const cd q1 = mk(r1.x, r1.y), q0 = mk(r0.x, r0.y);
+                        const cd fk = q1 * bk1 + q0 * bk0;
+                        const cd fg = q1 * bg1 + q0 * bg0;
+                        const double kx = row16_sum(fk.x), ky = row16_sum(fk.y);
+                        const double gx = row16_sum(fg.x), gy = row16_sum(fg.y);
+                        if (col == c) Kre[r] = kx, Kim[r] = ky, Gre[r] = gx, Gim[r] = gy;
+                    }
                 }
             }
-        }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (__ballot(match[r]) == 0ull) continue;  // wave-uniform
+                if (match[r]) split[r] = decide(r, lane, Kre[r], Kim[r], Gre[r], Gim[r], bad);
+            }
+            if (__ballot(split[0] || split[1] || split[2] || split[3]) != 0ull) {
+                if (n_next + 2 <= 64) {
+                    const unsigned long long c0 = path << 1;
+                    const unsigned int hi = ((unsigned)ccls << 30) | (unsigned)(c0 >> 32);
+                    // (values and positions are wave-uniform: a lane-select writes lane n_next / n_next + 1)
+                    enext_lo = lane == n_next ? (unsigned)c0 : (lane == n_next + 1 ? (unsigned)(c0 | 1ull) : enext_lo);
+                    enext_hi = (lane == n_next || lane == n_next + 1) ? hi : enext_hi;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (split[r]) mnext[r] |= 3ull << n_next;
+                    n_next += 2;
+                } else {
+                    // the next level's list is full: these integrals restart in the cooperative kernel
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (split[r]) {
+                            defer(r, depth, ccls, path);
+                            if (A.stats) atomicAdd(&A.stats[10], 1ull);
+                        }
+                }
+            }
 #ifdef EMME_DENSE_STAMPS
-        {
-            int stamp_dep2;
-            asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(stamp_dep2) : "v"((int)(unsigned)key[0]));
-            STAMP(ts3);
-            cyc_sel += ts1 - ts0;
-            if (dense_round) cyc_dense += ts2 - ts1; else cyc_sparse += ts2 - ts1;
-            cyc_dec += ts3 - ts2;
-        }
+            {
+                int dep2;
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep2) : "v"((int)(unsigned)mnext[0]));
+                STAMP(ts3);
+                cyc_sel += ts1 - ts0;
+                if (dense_round) cyc_dense += ts2 - ts1; else cyc_sparse += ts2 - ts1;
+                cyc_dec += ts3 - ts2;
+            }
 #endif
+        }
+        ecur_lo = enext_lo, ecur_hi = enext_hi;
+        n_cur = n_next;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mcur[r] = mnext[r], mnext[r] = 0ull;
     }
 
     // ---- results (include/solver.h:448-455: mat(i,j) = -kappa W_ij dx, mirrored) ---------------------
     unsigned long long my_intervals = 0;
+    const cd rdw = A.Mold ? rcp(mk(A.domega[b].x, A.domega[b].y)) : mk(0.0, 0.0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int pidx = tile * TILE_PAIRS + rho + 4 * r;
         if (has_w && pidx < A.npairs && !deferred[r]) {
-            my_intervals += (unsigned long long)count[r];
+            my_intervals += (unsigned long long)s_count[wave][r][lane];
             const ushort2 ij = A.pairs[pidx];
             const int i = ij.x, j = ij.y;
-            const cd kap = mk(P.pref * sum[r].y, -(P.pref * sum[r].x));  // -i pref sum, Parameters.cpp:182
+            const cd sm = mk(s_sumx[wave][r][lane], s_sumy[wave][r][lane]);
+            const cd kap = mk(P.pref * sm.y, -(P.pref * sm.x));  // -i pref sum, Parameters.cpp:182
             if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
-            // (the adiabatic-electron term kappa_e is zero for moment 0, src/Parameters.cpp:191-193)
             const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
-            store(i, j, v);
-            store(j, i, v);
+            store(i, j, v, rdw);
+            store(j, i, v, rdw);
         }
     }
     if (has_w) {
@@ -518,13 +544,14 @@ hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom&
 }
 
 hipError_t launch_btab(int nslots, const void* const ttab[2], const double* omega, const int* act_idx, int n_act,
-                       void* btab, hipStream_t stream) {
+                       const int* wmap, int nchunks, void* btab, hipStream_t stream) {
     BtabArgs A;
     A.ttab[0] = (const double2*)ttab[0], A.ttab[1] = (const double2*)ttab[1];
     A.omega = (const double2*)omega;
     A.act_idx = act_idx;
+    A.wmap = wmap;
     A.n_act = n_act;
-    A.nchunks = (n_act + 15) / 16;
+    A.nchunks = nchunks;
     A.nslots = nslots;
     A.btab = (double*)btab;
     const long total = (long)nslots * 16 * n_act;
@@ -539,7 +566,7 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1], const double* scale,
                                  const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
                                  unsigned long long* defer_info, const int* act_idx, int n_act,
-                                 unsigned long long* stats, hipStream_t stream) {
+                                 const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream) {
     DenseArgs A;
     A.P = L.P;
     A.pairs = (const ushort2*)L.pairs;
@@ -556,7 +583,8 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.defer_info = defer_info;
     A.act_idx = act_idx;
     A.n_act = n_act;
-    A.nchunks = (n_act + 15) / 16;
+    A.chunks = (const int2*)chunks;
+    A.nchunks = nchunks;
     A.omega = (const double2*)L.omega;
     A.M = (double2*)L.M;
     A.Mold = (const double2*)L.Mold;
@@ -569,8 +597,7 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.dense_min_cols = e ? std::atoi(e) : 3;
     const int ntiles = (L.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;
-    const long blocks = (long)((ntg + 7) / 8) * A.nchunks * 8;
-    hipLaunchKernelGGL(k_assemble_dense, dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(k_assemble_dense, dim3((unsigned)((long)ntg * A.nchunks)), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 

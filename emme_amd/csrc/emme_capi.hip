@@ -294,7 +294,7 @@ int ensure_batch(emme_ctx* c, int nb) {
     HIP_TRY(malloc_retry((void**)&c->d_status, sizeof(int) * nb));
     HIP_TRY(malloc_retry((void**)&c->d_intervals, sizeof(unsigned long long) * nb));
     HIP_TRY(malloc_retry((void**)&c->d_actidx, sizeof(int) * nb));
-    HIP_TRY(malloc_retry((void**)&c->d_chunks, sizeof(int) * 2 * nb));
+    HIP_TRY(malloc_retry((void**)&c->d_chunks, sizeof(int) * 3 * nb));  // (first, size) per chunk | position map
     {
         if (c->p_act) (void)hipHostFree(c->p_act);
         if (c->p_iv) (void)hipHostFree(c->p_iv);
@@ -304,9 +304,9 @@ int ensure_batch(emme_ctx* c, int nb) {
         HIP_TRY(hipHostMalloc((void**)&c->p_act, sizeof(int) * nb));
         HIP_TRY(hipHostMalloc((void**)&c->p_iv, sizeof(unsigned long long) * nb));
         HIP_TRY(hipHostMalloc((void**)&c->p_w, sizeof(double) * 2 * nb));
-        HIP_TRY(hipHostMalloc((void**)&c->p_lists, sizeof(int) * 2 * 3 * nb));  // 2 slots x (order | chunks)
+        HIP_TRY(hipHostMalloc((void**)&c->p_lists, sizeof(int) * 2 * 4 * nb));  // 2 slots x (order | chunks | map)
         if (!c->p_deferred) HIP_TRY(hipHostMalloc((void**)&c->p_deferred, sizeof(unsigned int)));
-        c->p_cap = nb, c->p_lists_cap = 3 * nb;
+        c->p_cap = nb, c->p_lists_cap = 4 * nb;
     }
     if (!c->d_rounds) {
         HIP_TRY(malloc_retry((void**)&c->d_rounds, 16 * sizeof(unsigned long long)));
@@ -683,10 +683,24 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             std::vector<unsigned long long> sorted = cs;
             std::sort(sorted.begin(), sorted.end());
             const double typical = (double)std::max<unsigned long long>(sorted[sorted.size() / 2], 1ull);
+            // dense fill: one wave walks a (16-pair tile, chunk) serially, so (a) a chunk of omegas whose
+            // trees do not overlap costs the SUM of their walks in one wave -- expensive omegas get narrow
+            // chunks like in the independent-lane kernels -- and (b) a launch needs several times more
+            // tile tasks than the chip holds waves: the widest chunk shrinks until there are
+            int dense_cap = gw;
+            if (c->tiled) {
+                const long ntiles = (c->npairs + 15) / 16;
+                const char* tt = std::getenv("EMME_DENSE_MIN_TASKS");
+                const long min_tasks = tt ? std::atol(tt) : 8000;
+                while (dense_cap > 2 && ((long)idx.size() + dense_cap - 1) / dense_cap * ntiles < min_tasks) dense_cap >>= 1;
+            }
+            static const double dense_ratio = std::getenv("EMME_DENSE_COST_RATIO") ? std::atof(std::getenv("EMME_DENSE_COST_RATIO")) : 3.0;
             size_t q = 0;
             while (q < idx.size()) {
-                int cap = gw;
-                while (!union_walk && cap > 1 && (double)cs[q] * cap > typical * gw * 1.5) cap >>= 1;
+                int cap = c->tiled ? dense_cap : gw;
+                while ((!union_walk || c->tiled) && cap > (c->tiled ? 2 : 1) &&
+                       (double)cs[q] * cap > typical * gw * (c->tiled ? dense_ratio : 1.5))
+                    cap >>= 1;
                 const int n = (int)std::min<size_t>((size_t)cap, idx.size() - q);
                 ch.push_back((int)q);
                 ch.push_back(n);
@@ -710,7 +724,13 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             int* slot = c->p_lists + (size_t)(c->p_lists_turn++ & 1u) * c->p_lists_cap;
             std::copy(idx.begin(), idx.end(), slot);
             std::copy(ch.begin(), ch.end(), slot + n_lane);
-            HIP_TRY(launch_stage_ints(slot, c->d_actidx, n_lane, c->d_chunks, (int)ch.size(), c->stream));
+            int n2 = (int)ch.size();
+            if (c->tiled) {  // dense fill: position -> (chunk, column) map behind the chunk table
+                for (int k = 0; k < nchunks; ++k)
+                    for (int w = 0; w < ch[2 * k + 1]; ++w) slot[n_lane + n2 + ch[2 * k] + w] = (k << 8) | w;
+                n2 += n_lane;
+            }
+            HIP_TRY(launch_stage_ints(slot, c->d_actidx, n_lane, c->d_chunks, n2, c->stream));
         }
         HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
         c->last_fill_mode = c->tiled ? 4 : (union_walk ? 3 : 2);
@@ -718,7 +738,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             // dense fill: weighted phase tables for every cached interval and omega chunk, then one wave
             // per (16-pair tile, 16-omega chunk); chunk c = positions 16 c .. of the cost-sorted list
             const int n_int = node_cache_intervals(c->cache_geom);
-            const int nch = (n_lane + 15) / 16;
+            const int nch = nchunks;
             const size_t need = btab_bytes(n_int, nch);
             if (need > c->btab_cap) {
                 if (c->d_btab) (void)hipFree(c->d_btab);
@@ -728,13 +748,14 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             }
             {
                 ScopedSpan s(c, K_OTHER);
-                HIP_TRY(launch_btab(n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_btab, c->stream));
+                HIP_TRY(launch_btab(n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_chunks + 2 * nchunks, nchunks,
+                                    c->d_btab, c->stream));
             }
             {
                 ScopedSpan s(c, K_ASM);
                 HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
-                                              c->d_rounds, c->stream));
+                                              c->d_chunks, nchunks, c->d_rounds, c->stream));
             }
         } else if (n_lane && c->folded) {
             // phase table of this launch: exp(T omega) for every cached interval, node and omega
@@ -854,14 +875,12 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->em_shared = !es && !(std::getenv("EMME_EM_SHARED") && std::atoi(std::getenv("EMME_EM_SHARED")) == 0);
     // EMME_PHASE_TABLE=0: unfolded records and exp(A0 + T omega) per (pair, node, omega) in the fill
     c->folded = !(std::getenv("EMME_PHASE_TABLE") && std::atoi(std::getenv("EMME_PHASE_TABLE")) == 0);
-    // EMME_DENSE=1: electrostatic GK15 on folded records through the tiled layout + dense fill on the
-    // FP64 matrix cores (assemble_dense.hip) instead of the union walk.  EXPERIMENTAL, off by default:
-    // faster on batches whose omegas have overlapping trees (the bootstrap fills of the bench: 1.17 /
-    // 1.37 ms against 1.58 / 2.18), slower as soon as chains wander.  It carries the
-    // safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature goal is tighter
-    // than 1e-9 never take it.
+    // electrostatic GK15 on folded records: tiled record layout + dense fill on the FP64 matrix cores
+    // (assemble_dense.hip) instead of the union walk (EMME_DENSE=0 restores that).  It
+    // carries the safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature goal
+    // (integration_accuracy) is tighter than 1e-9 keep the exact union kernel.
     c->tiled = es && p->integration_start_points == 15 && c->folded && p->integration_accuracy >= 1e-9 &&
-               (std::getenv("EMME_DENSE") && std::atoi(std::getenv("EMME_DENSE")) == 1) &&
+               !(std::getenv("EMME_DENSE") && std::atoi(std::getenv("EMME_DENSE")) == 0) &&
                !(std::getenv("EMME_UNION") && std::atoi(std::getenv("EMME_UNION")) == 0);
 
     DevParams& P = c->P;
@@ -976,6 +995,8 @@ int emme_ctx_profile_read(emme_ctx_t* c, emme_profile_t* out, int reset) {
     if (c->d_rounds) {
         unsigned long long r[16] = {};
         HIP_TRY(hipMemcpy(r, c->d_rounds, sizeof r, hipMemcpyDeviceToHost));
+        if (std::getenv("EMME_DEBUG_STAMPS") && r[10])
+            fprintf(stderr, "[emme] dense fill: %llu integrals handed over because a level list overflowed\n", r[10]);
         if (std::getenv("EMME_DEBUG_STAMPS") && r[8])  // diagnostic build (EMME_DENSE_STAMPS) only
             fprintf(stderr, "[emme] dense stamps: select %.3g  dense %.3g  sparse %.3g  decide %.3g  task total %.3g  "
                     "longest task %.3g cycles; per round: select %.0f dense %.0f sparse %.0f decide %.0f\n",

@@ -92,15 +92,16 @@ hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom&
                                    void* recs, void* ttab, double* scale, hipStream_t stream);
 // weighted phase tables of one launch: btab_bytes(cached intervals, ceil(n_act / 16))
 size_t btab_bytes(int nslots, int nchunks);
+// wmap[position in the omega list] = chunk << 8 | column of that omega
 hipError_t launch_btab(int nslots, const void* const ttab[2], const double* omega, const int* act_idx,
-                       int n_act, void* btab, hipStream_t stream);
-// act_idx: the launch's omegas, cost-sorted; chunk c = positions 16 c .. 16 c + 15.  stats (nullable):
-// 4 counters (dense rounds, sparse rounds, sparse columns, tile tasks)
+                       int n_act, const int* wmap, int nchunks, void* btab, hipStream_t stream);
+// act_idx: the launch's omegas, cost-sorted; chunks: int2 (first position, size <= 16) per chunk.
+// stats (nullable): counters (dense rounds, vector rounds, vector columns, tile tasks, ...)
 hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1], const double* scale,
                                  const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
                                  unsigned long long* defer_info, const int* act_idx, int n_act,
-                                 unsigned long long* stats, hipStream_t stream);
+                                 const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,

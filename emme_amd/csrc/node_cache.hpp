@@ -67,7 +67,7 @@ struct CacheGeom {
 // ---- tiled layout (electrostatic GK15, dense fill: assemble_dense.hip) ---------------------------
 // The records of TILE_PAIRS = 16 consecutive pairs of the pair list and one interval form one
 // block of TILE_BLOCK doubles, laid out as the A operand of v_mfma_f64_16x16x4_f64 wants it:
-//     Qre[k = 0..31][p = 0..15] | Qim[32][16] | ReA0[lane 0..15][p 0..15]
+//     Q[k = 0..31][p = 0..15] as (re, im) pairs | ReA0[lane 0..15][p 0..15]
 // k = 2 sn + which: sn = node slot in GAUSS-FIRST order (centre, +-x2, +-x4, +-x6, then +-x1, +-x3,
 // +-x5, +-x7; sn 15 = zero padding), which = 0: exp(A0) Q1, 1: exp(A0) Q0 (the folded amplitudes),
 // so that rows 0..13 are the embedded Gauss rule's and K = Q . BK, G = Q[0:16] . BG are plain
@@ -82,7 +82,7 @@ __host__ __device__ inline int slotnode_of_lane(int lane) {
     return (q & 1) ? 6 + q + neg : q - 1 + neg;
 }
 // per-launch table of weighted phases, one block per (interval slot, omega chunk of 16):
-//     BKre[32][16] | BKim[32][16] | BGre[16][16] | BGim[16][16]        (row k, column omega)
+//     BK[32][16] | BG[16][16]   as (re, im) pairs        (row k, column omega)
 // rows 2 sn / 2 sn + 1 = wk (omega E) / wk E of node sn, BG the same with the Gauss weights
 constexpr int BTAB_BLOCK = 2 * 32 * 16 + 2 * 16 * 16;  // doubles: 12 KB
 

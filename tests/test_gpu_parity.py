@@ -393,13 +393,15 @@ KERNEL_MODES = {
     # HBM node cache, folded records + phase table; electrostatic GK15: union-walk kernel, EM / GK31:
     # independent lanes (the defaults); uncached integrals via the work list
     "cached": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1"},
-    # electrostatic GK15 cases through the experimental dense (matrix-core) fill on the tiled cache
-    # layout: default routing, every round on the vector path, every round on the matrix cores
-    "cached-dense": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1"},
-    "cached-dense-all-sparse": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1", "EMME_DENSE_MIN_COLS": "17"},
-    "cached-dense-all-mfma": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "1", "EMME_DENSE_MIN_COLS": "1"},
-    "cached-dense-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_DENSE": "1",
-                          "EMME_CACHE_MIN_DEPTH": "0"},
+    # electrostatic GK15 cases ("cached" takes the dense matrix-core fill on the tiled layout for them):
+    # every round on the vector path, every round on the matrix cores, one omega per chunk, and the
+    # union-walk kernel on the per-pair layout instead
+    "cached-dense-all-sparse": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE_MIN_COLS": "17"},
+    "cached-dense-all-mfma": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE_MIN_COLS": "1"},
+    "cached-dense-narrow": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE_MIN_TASKS": "100000000"},
+    "cached-dense-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_CACHE_MIN_DEPTH": "0"},
+    "cached-union": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "0"},
+    "cached-union-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_DENSE": "0", "EMME_CACHE_MIN_DEPTH": "0"},
     # the same with the independent-lane kernel for every case
     "cached-independent": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
     # unfolded records, exp(A0 + T omega) evaluated per (pair, node, omega) in the fill
@@ -448,6 +450,7 @@ def test_union_fill_bits_do_not_depend_on_intervals_per_round(emme, monkeypatch)
     are the same bit for bit -- also for omegas whose trees barely overlap."""
     monkeypatch.setenv("EMME_NODE_CACHE_GB", "8")
     monkeypatch.setenv("EMME_WL_MIN", "1")
+    monkeypatch.setenv("EMME_DENSE", "0")  # the union-walk kernel itself (the default for these inputs is the dense fill)
     d = example_tokamak(npoints=48)
     rng = np.random.default_rng(3)
     ws = np.concatenate([rng.uniform(-1.2, -0.4, 20) + 1j * rng.uniform(0.05, 0.4, 20),
