@@ -80,12 +80,10 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
         const double2* q = reinterpret_cast<const double2*>(blk);
         const double2 r1 = q[(2 * sn) * 16 + p], r0 = q[(2 * sn + 1) * 16 + p];
         const cd q1 = mk(r1.x, r1.y), q0 = mk(r0.x, r0.y);
-        const double rea0 = blk[1024 + lane_in_group * 16 + p];
         const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
         const cd arg = mk(tt.x, tt.y) * oc.omega;
-        if (!(rea0 + arg.x >= -40.)) {
-            if (rea0 + arg.x < -40.) return mk(0.0, 0.0);  // safe_exp clamp, src/Parameters.cpp:167-173
-        }
+        // (no safe_exp clamp on tiled records, like the dense fill that shares them: node_cache.hpp;
+        // exp(T omega) below -745 underflows to an exact 0 by itself)
         double sa, ca;
         fsincos(arg.y, sa, ca, tc);
         const double ea = fexp(arg.x, tc);

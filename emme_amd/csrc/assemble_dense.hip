@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
         const long item = tile * TILE_PAIRS + p;
         double* blk = A.recs + ti * TILE_BLOCK;
         cd q1 = mk(0.0, 0.0), q0 = mk(0.0, 0.0);
-        double rea0 = -1.0e300;  // "always clamped"
         int depth;
         unsigned long long path;
         A.geom.interval(A.part, idx, depth, path);
@@ -107,11 +106,10 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
                 const double ea = exp(fmin(d.A0.x, 700.0));
                 const cd ex = mk(ea * ca, ea * sa);
                 q1 = ex * d.Q1, q0 = ex * d.Q0;
-                rea0 = d.A0.x;
                 if (!(isfinite(q1.x) && isfinite(q1.y) && isfinite(q0.x) && isfinite(q0.y))) {
                     // exp(A0) = 0 against an overflowing amplitude: the reference's clamp makes this
                     // node contribute exactly 0 for every omega the integrand is finite for
-                    q1 = mk(0.0, 0.0), q0 = mk(0.0, 0.0), rea0 = -1.0e300;
+                    q1 = mk(0.0, 0.0), q0 = mk(0.0, 0.0);
                 }
             }
             if (item == 0) {
@@ -122,7 +120,6 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
         double2* q = reinterpret_cast<double2*>(blk);
         q[(2 * sn) * 16 + p] = make_double2(q1.x, q1.y);
         q[(2 * sn + 1) * 16 + p] = make_double2(q0.x, q0.y);
-        blk[1024 + lane * 16 + p] = rea0;
     }
 }
 

@@ -67,14 +67,15 @@ struct CacheGeom {
 // ---- tiled layout (electrostatic GK15, dense fill: assemble_dense.hip) ---------------------------
 // The records of TILE_PAIRS = 16 consecutive pairs of the pair list and one interval form one
 // block of TILE_BLOCK doubles, laid out as the A operand of v_mfma_f64_16x16x4_f64 wants it:
-//     Q[k = 0..31][p = 0..15] as (re, im) pairs | ReA0[lane 0..15][p 0..15]
+//     Q[k = 0..31][p = 0..15] as (re, im) pairs
 // k = 2 sn + which: sn = node slot in GAUSS-FIRST order (centre, +-x2, +-x4, +-x6, then +-x1, +-x3,
 // +-x5, +-x7; sn 15 = zero padding), which = 0: exp(A0) Q1, 1: exp(A0) Q0 (the folded amplitudes),
 // so that rows 0..13 are the embedded Gauss rule's and K = Q . BK, G = Q[0:16] . BG are plain
-// complex GEMMs against per-launch tables of weighted phases (k_btab).  ReA0 (for the exact
-// safe_exp clamp of the cooperative kernel) is indexed by the node's LANE of gk_lane<15>.
+// complex GEMMs against per-launch tables of weighted phases (k_btab).  Re A0 is not kept: neither the
+// dense fill nor the cooperative kernel applies the safe_exp clamp to tiled records (the clamped tails are
+// <= 4e-14 absolute, assemble_dense.hip), and records that are not finite are zeroed when they are built.
 constexpr int TILE_PAIRS = 16;
-constexpr int TILE_BLOCK = 2 * 32 * 16 + 16 * 16;  // doubles: 10 KB per (tile, interval)
+constexpr int TILE_BLOCK = 2 * 32 * 16;  // doubles: 8 KB per (tile, interval)
 __host__ __device__ inline int slotnode_of_lane(int lane) {
     if (lane >= 15) return 15;
     const int q = lane < 8 ? lane : lane - 7, neg = lane >= 8 ? 1 : 0;
