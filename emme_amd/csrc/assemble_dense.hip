@@ -11,7 +11,7 @@
 // (include/solver.h:446-455 fills them one task each) and walks the UNION of their adaptive trees in
 // pre-order, one interval per round:
 //   dense round  (the interval is in the trees of >= 3 omega columns): 48 v_mfma_f64_16x16x4_f64 --
-//                 32 for K (k = 32), 16 for G (k = 16) -- fed by 20 coalesced 1-KB loads, no
+//                 32 for K (k = 32), 16 for G (k = 16) -- fed by 16 coalesced 1-KB loads, no
 //                 per-element address or key arithmetic at all;
 //   sparse round (1-2 columns: a chain that has wandered to a damped omega refines where nobody
 //                 else does): lane = node, DPP row sums, 16 pairs of one omega at a time;
@@ -163,12 +163,15 @@ __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
         double2* bk = reinterpret_cast<double2*>(blk);
         bk[(2 * sn) * 16 + col] = make_double2(gk.wk * we.x, gk.wk * we.y);
         bk[(2 * sn + 1) * 16 + col] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
-        if (sn < 8) {  // rows 0..15 of the Gauss table (sn 7 is a Kronrod-only node: wg = 0)
-            double2* bg = bk + 512;
-            bg[(2 * sn) * 16 + col] = make_double2(gk.wg * we.x, gk.wg * we.y);
-            bg[(2 * sn + 1) * 16 + col] = make_double2(gk.wg * ev.x, gk.wg * ev.y);
-        }
+
     }
+}
+
+// (wg / wk) of node slot sn: the Gauss rule's weight relative to the Kronrod weight; 0 for Kronrod-only nodes
+__device__ __forceinline__ double gauss_ratio(int sn) {
+    if (sn > 6) return 0.0;
+    const int q = sn == 0 ? 0 : ((sn + 1) & ~1);  // slots (1,2) (3,4) (5,6) are nodes +-x2, +-x4, +-x6
+    return kWg15[q >> 1] / kWk15[q];
 }
 
 struct DenseArgs {
@@ -217,7 +220,7 @@ __device__ __forceinline__ double fsqrt_pos(double x) {
 }
 
 #ifndef EMME_DENSE_MIN_WAVES
-#define EMME_DENSE_MIN_WAVES 3
+#define EMME_DENSE_MIN_WAVES 2
 #endif
 
 __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(DenseArgs A) {
@@ -254,6 +257,11 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     }
 
     const double inv_scale = 2. / (M_PI / 2.0);
+    // (wg / wk) of this lane's rows: as MFMA A operand (row 4 ks + (lane >> 4), ks < 4) and as node lane & 15
+    double grat[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) grat[ks] = gauss_ratio((4 * ks + (lane >> 4)) >> 1);
+    const double grat_node = gauss_ratio(col);
     // ---- the wave's 256 integrals: element r of this lane = (pair tile*16 + rho + 4 r, omega col) -----
     unsigned long long mcur[4], mnext[4];  // entries of the current / next level this element needs
     // per-element accumulators live in LDS (touched only by their owner lane, only when the element owns
@@ -334,6 +342,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             STAMP(ts1);
             if (dense_round) {
                 ++n_dense;
+                v4d K2re = {0.0, 0.0, 0.0, 0.0}, K2im = K2re, G2re = K2re, G2im = K2re;
                 // k-steps 0..3 feed K and G (the embedded Gauss rule lives in rows 0..15), 4..7 only K; all 20
                 // operand loads are issued before the first MFMA (one exposed latency per entry, not four)
 #pragma unroll
@@ -343,19 +352,21 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[k * 16 + p], B[k][w] = b2[k * 16 + w]:
                         // both are base + 64 ks + lane in (re, im) pairs -- ONE coalesced 1-KB load each
                         const double2 a = a2[64 * ks + lane], bk = b2[64 * ks + lane];
+                        // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
                         Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
                         Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
-                        Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, Kre, 0, 0, 0);
-                        Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, Kim, 0, 0, 0);
-                        if (ks < 4) {
-                            const double2 bg = b2[512 + 64 * ks + lane];
-                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bg.x, Gre, 0, 0, 0);
-                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bg.y, Gim, 0, 0, 0);
-                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bg.y, Gre, 0, 0, 0);
-                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bg.x, Gim, 0, 0, 0);
+                        K2re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, K2re, 0, 0, 0);
+                        K2im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, K2im, 0, 0, 0);
+                        if (ks < 4) {  // G = sum_k (rho_k Q[p][k]) BK[k][w]: the A operand scaled, the same B
+                            const double gx = a.x * grat[ks], gy = a.y * grat[ks];
+                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.x, Gre, 0, 0, 0);
+                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.y, Gim, 0, 0, 0);
+                            G2re = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, -bk.y, G2re, 0, 0, 0);
+                            G2im = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, bk.x, G2im, 0, 0, 0);
                         }
                     }
                 }
+                Kre += K2re, Kim += K2im, Gre += G2re, Gim += G2im;
             }
             // ---- every element that owns the interval decides for itself (include/functions.h:203-208,
             // 231-247); an entry somebody splits puts its two children on the next level's list
@@ -386,13 +397,6 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 }
                 return sp;
             };
-#ifdef EMME_DENSE_STAMPS
-            if (dense_round) {  // (make the stamp wait for the sums)
-                int dep;
-                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep) : "v"(__double2loint(Kre[0] + Gim[3])));
-            }
-#endif
-            STAMP(ts2);
             if (!dense_round) {
                 // ---- vector round (one or two omega columns own the interval: a chain that wandered to a
                 // damped omega refines where nobody else does): lane = node (sn = lane & 15), row rho takes
@@ -408,11 +412,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     ++n_cols;
                     const double2 k1 = b2[(2 * sn) * 16 + c], k0 = b2[(2 * sn + 1) * 16 + c];
                     const cd bk1 = mk(k1.x, k1.y), bk0 = mk(k0.x, k0.y);
-                    cd bg1 = mk(0.0, 0.0), bg0 = mk(0.0, 0.0);
-                    if (sn < 8) {
-                        const double2 g1 = b2[512 + (2 * sn) * 16 + c], g0 = b2[512 + (2 * sn + 1) * 16 + c];
-                        bg1 = mk(g1.x, g1.y), bg0 = mk(g0.x, g0.y);
-                    }
+                    const cd bg1 = grat_node * bk1, bg0 = grat_node * bk0;  // the Gauss rows: (wg / wk) times BK's
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int p = rho + 4 * r;  // (re-read per column from L1: a vector round rarely has two)
@@ -426,6 +426,13 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     }
                 }
             }
+#ifdef EMME_DENSE_STAMPS
+            {  // (make the stamp wait for the sums)
+                int dep;
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep) : "v"(__double2loint(Kre[0] + Gim[3])));
+            }
+#endif
+            STAMP(ts2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (__ballot(match[r]) == 0ull) continue;  // wave-uniform

@@ -83,9 +83,10 @@ __host__ __device__ inline int slotnode_of_lane(int lane) {
     return (q & 1) ? 6 + q + neg : q - 1 + neg;
 }
 // per-launch table of weighted phases, one block per (interval slot, omega chunk of 16):
-//     BK[32][16] | BG[16][16]   as (re, im) pairs        (row k, column omega)
-// rows 2 sn / 2 sn + 1 = wk (omega E) / wk E of node sn, BG the same with the Gauss weights
-constexpr int BTAB_BLOCK = 2 * 32 * 16 + 2 * 16 * 16;  // doubles: 12 KB
+//     BK[32][16] as (re, im) pairs        (row k, column omega)
+// rows 2 sn / 2 sn + 1 = wk (omega E) / wk E of node sn.  The embedded Gauss rule needs no table of its
+// own: its row k is (wg / wk)_k times BK's, a per-row constant that the fill applies to the A operand.
+constexpr int BTAB_BLOCK = 2 * 32 * 16;  // doubles: 8 KB
 
 inline CacheGeom make_geom(const NodeCacheGeom& g) {
     CacheGeom c;
