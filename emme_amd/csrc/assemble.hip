@@ -77,9 +77,8 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
             which < 0 ? tb + ((size_t)tile * A.geom.ni_main() + cslot) * TILE_BLOCK
                       : tb + ((size_t)tile * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * TILE_BLOCK;
         const int sn = slotnode_of_lane(lane_in_group);
-        const double2* q = reinterpret_cast<const double2*>(blk);
-        const double2 r1 = q[(2 * sn) * 16 + p], r0 = q[(2 * sn + 1) * 16 + p];
-        const cd q1 = mk(r1.x, r1.y), q0 = mk(r0.x, r0.y);
+        const double4 ra = *reinterpret_cast<const double4*>(reinterpret_cast<const double2*>(blk) + tile_index(2 * sn, p));
+        const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);  // (Q1, Q0) of the node: one 32-byte piece
         const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
         const cd arg = mk(tt.x, tt.y) * oc.omega;
         // (no safe_exp clamp on tiled records, like the dense fill that shares them: node_cache.hpp;

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
             }
         }
         double2* q = reinterpret_cast<double2*>(blk);
-        q[(2 * sn) * 16 + p] = make_double2(q1.x, q1.y);
-        q[(2 * sn + 1) * 16 + p] = make_double2(q0.x, q0.y);
+        q[tile_index(2 * sn, p)] = make_double2(q1.x, q1.y);
+        q[tile_index(2 * sn + 1, p)] = make_double2(q0.x, q0.y);
     }
 }
 
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
         double* blk = A.btab + ((size_t)slot * A.nchunks + (wm >> 8)) * BTAB_BLOCK;
         const int col = wm & 255;
         double2* bk = reinterpret_cast<double2*>(blk);
-        bk[(2 * sn) * 16 + col] = make_double2(gk.wk * we.x, gk.wk * we.y);
-        bk[(2 * sn + 1) * 16 + col] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
+        bk[tile_index(2 * sn, col)] = make_double2(gk.wk * we.x, gk.wk * we.y);
+        bk[tile_index(2 * sn + 1, col)] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
 
     }
 }
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) grat[ks] = gauss_ratio((4 * ks + (lane >> 4)) >> 1);
     const double grat_node = gauss_ratio(col);
+    const int loff = tile_index(lane >> 4, lane & 15);  // this lane's element of an MFMA operand load, k-step 0
     // ---- the wave's 256 integrals: element r of this lane = (pair tile*16 + rho + 4 r, omega col) -----
     unsigned long long mcur[4], mnext[4];  // entries of the current / next level this element needs
     // per-element accumulators live in LDS (touched only by their owner lane, only when the element owns
@@ -349,9 +350,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 for (int kp = 0; kp < 4; ++kp) {
 #pragma unroll
                     for (int ks = 2 * kp; ks < 2 * kp + 2; ++ks) {
-                        // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[k * 16 + p], B[k][w] = b2[k * 16 + w]:
-                        // both are base + 64 ks + lane in (re, im) pairs -- ONE coalesced 1-KB load each
-                        const double2 a = a2[64 * ks + lane], bk = b2[64 * ks + lane];
+                        // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[tile_index(k, p)], B[k][w] likewise:
+                        // both are base + 64 ks + loff in (re, im) pairs -- ONE coalesced 1-KB load each
+                        const double2 a = a2[64 * ks + loff], bk = b2[64 * ks + loff];
                         // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
                         Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
                         Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
@@ -410,14 +411,14 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     const int c = __builtin_ctz(colmask);
                     colmask &= colmask - 1;
                     ++n_cols;
-                    const double2 k1 = b2[(2 * sn) * 16 + c], k0 = b2[(2 * sn + 1) * 16 + c];
-                    const cd bk1 = mk(k1.x, k1.y), bk0 = mk(k0.x, k0.y);
+                    const double4 kb = *reinterpret_cast<const double4*>(b2 + tile_index(2 * sn, c));  // (BK1, BK0) of the node
+                    const cd bk1 = mk(kb.x, kb.y), bk0 = mk(kb.z, kb.w);
                     const cd bg1 = grat_node * bk1, bg0 = grat_node * bk0;  // the Gauss rows: (wg / wk) times BK's
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int p = rho + 4 * r;  // (re-read per column from L1: a vector round rarely has two)
-                        const double2 r1 = a2[(2 * sn) * 16 + p], r0 = a2[(2 * sn + 1) * 16 + p];
-                        const cd q1 = mk(r1.x, r1.y), q0 = mk(r0.x, r0.y);
+                        const double4 ra = *reinterpret_cast<const double4*>(a2 + tile_index(2 * sn, p));  // (Q1, Q0): 32 bytes
+                        const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);
                         const cd fk = q1 * bk1 + q0 * bk0;
                         const cd fg = q1 * bg1 + q0 * bg0;
                         const double kx = row16_sum(fk.x), ky = row16_sum(fk.y);

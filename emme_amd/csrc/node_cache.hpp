@@ -67,7 +67,7 @@ struct CacheGeom {
 // ---- tiled layout (electrostatic GK15, dense fill: assemble_dense.hip) ---------------------------
 // The records of TILE_PAIRS = 16 consecutive pairs of the pair list and one interval form one
 // block of TILE_BLOCK doubles, laid out as the A operand of v_mfma_f64_16x16x4_f64 wants it:
-//     Q[k = 0..31][p = 0..15] as (re, im) pairs
+//     Q[sn = 0..15][p = 0..15][which = 0, 1] as (re, im) pairs   (row k = 2 sn + which of the GEMM)
 // k = 2 sn + which: sn = node slot in GAUSS-FIRST order (centre, +-x2, +-x4, +-x6, then +-x1, +-x3,
 // +-x5, +-x7; sn 15 = zero padding), which = 0: exp(A0) Q1, 1: exp(A0) Q0 (the folded amplitudes),
 // so that rows 0..13 are the embedded Gauss rule's and K = Q . BK, G = Q[0:16] . BG are plain
@@ -83,10 +83,14 @@ __host__ __device__ inline int slotnode_of_lane(int lane) {
     return (q & 1) ? 6 + q + neg : q - 1 + neg;
 }
 // per-launch table of weighted phases, one block per (interval slot, omega chunk of 16):
-//     BK[32][16] as (re, im) pairs        (row k, column omega)
+//     BK[sn][column omega][which] as (re, im) pairs   (row k = 2 sn + which), same index map as the records:
 // rows 2 sn / 2 sn + 1 = wk (omega E) / wk E of node sn.  The embedded Gauss rule needs no table of its
 // own: its row k is (wg / wk)_k times BK's, a per-row constant that the fill applies to the A operand.
 constexpr int BTAB_BLOCK = 2 * 32 * 16;  // doubles: 8 KB
+// element (row k, column / pair j) of a record or phase block, in (re, im) pairs.  The two rows of a node sit
+// side by side: the vector rounds and the cooperative kernel read a node's (Q1, Q0) as ONE 32-byte piece,
+// and the 64 lanes of an MFMA operand load (k = 4 ks + (lane >> 4), j = lane & 15) still cover 1 KB exactly.
+__host__ __device__ inline int tile_index(int k, int j) { return ((((k >> 1) << 4) + j) << 1) | (k & 1); }
 
 inline CacheGeom make_geom(const NodeCacheGeom& g) {
     CacheGeom c;
