@@ -467,7 +467,9 @@ def main():
             # algorithmic convention of SURVEY 8(d): integrand evaluations the REFERENCE algorithm performs
             # for these matrices (counted exactly by the kernels: GK intervals x nodes) x 900 flop-eq
             alg_tf = evals * FLOP_PER_EVAL / fill_s / 1e12 if fill_s > 0 else 0.0
-            roof = {"bound": "fp64-valu", "kernel": kname,
+            # the dense fill issues most of its flop on the FP64 matrix cores (whose dense peak equals the
+            # FP64 vector peak on MI355X: 78.6 TFLOP/s); the other fill kernels are vector-only
+            roof = {"bound": "mfma" if kname == "k_assemble_dense" else "fp64-valu", "kernel": kname,
                     "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                     "avg_launch_ms": avg_launch_s * 1e3, "launches": prof.assemble_launches,
                     "algorithmic_speedup_vs_fp64_peak": alg_tf / FP64_VECTOR_PEAK_TF,
@@ -481,10 +483,13 @@ def main():
                     "lane_utilisation": pm.get("lane_utilisation"),
                     "fp64_share_of_valu_instructions": pm.get("fp64_share_of_valu"),
                     "fp64_flop_issued_per_launch": pm["fp64_flop_issued_per_launch"],
+                    "mfma_share_of_flop": (pm.get("fp64_mfma_flop_per_launch", 0.0) / pm["fp64_flop_issued_per_launch"]
+                                           if pm["fp64_flop_issued_per_launch"] else None),
+                    "mfma_busy_per_wave_cycle": pm.get("SQ_VALU_MFMA_BUSY_CYCLES_per_wave_cycle"),
                     "traffic": pm.get("hbm_fetch_bytes_per_launch", 0.0) + pm.get("hbm_write_bytes_per_launch", 0.0),
                     "traffic_corrected": 2.0 * pm.get("hbm_fetch_bytes_per_launch", 0.0) + pm.get("hbm_write_bytes_per_launch", 0.0),
                     "note": "EXECUTED work: FP64 operations issued by the dominant fill kernel per launch (rocprofv3 "
-                            "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2 flop, + MFMA F64 ops; "
+                            "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2 flop, + 512 x SQ_INSTS_VALU_MFMA_MOPS_F64; "
                             f"{os.path.relpath(PMC_SUMMARY, ROOT)}, same workload) / hipEvent launch duration measured "
                             "in THIS run / fp64 vector peak.  frac_useful_lanes = x lane utilisation.  `traffic` = raw "
                             "FETCH_SIZE + WRITE_SIZE per launch, traffic_corrected with the gfx950 x2 read correction. "

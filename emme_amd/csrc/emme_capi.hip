@@ -473,8 +473,10 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         // from-scratch kernel and is SLOWER than no cache at all (measured, N = 1024, where only depth 4
         // fits: 83 omega-points/s with that cache against 335 through the omega-lane kernel,
         // profiles/r02_size_sweep.jsonl): below that the context runs uncached (EMME_CACHE_MIN_DEPTH)
+        // (tiled contexts: 6 -- their records are a third smaller, so depth 5 does fit at N = 1024, and is
+        // as bad there: 97 omega-points/s)
         const char* md = std::getenv("EMME_CACHE_MIN_DEPTH");
-        const int min_depth = md ? std::atoi(md) : 5;
+        const int min_depth = md ? std::atoi(md) : (c->tiled ? 6 : 5);
         bool found = false;
         for (const auto& o : options) {
             if (o[0] < min_depth) break;

@@ -42,6 +42,7 @@ for k, c in acc.items():
         f64 = sum(c.get("SQ_INSTS_VALU_%s_F64" % t, 0.0) for t in ("ADD", "MUL", "FMA", "TRANS"))
         flop = 64.0 * (f64 + c.get("SQ_INSTS_VALU_FMA_F64", 0.0)) + 512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
         d["fp64_flop_issued_per_launch"] = flop / n
+        d["fp64_mfma_flop_per_launch"] = 512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / n
         d["fp64_valu_insts_per_launch"] = f64 / n
         d["valu_insts_per_launch"] = c.get("SQ_INSTS_VALU", 0.0) / n
         if c.get("SQ_INSTS_VALU"):
