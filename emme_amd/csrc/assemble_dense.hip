@@ -7,11 +7,12 @@
 // with Q[p, 2n] = exp(A0) Q1, Q[p, 2n+1] = exp(A0) Q0 (omega-independent, HBM node cache) and
 // BK[2n, w] = wk_n w E[n, w], BK[2n+1, w] = wk_n E[n, w], E = exp(T_n w) (pair-independent, one
 // table per launch): a complex 16 x 16 x 32 GEMM per (16 pairs, 16 omegas, interval).  One wave owns
-// a TILE of 16 consecutive pairs x one chunk of 16 cost-sorted omegas = 256 integrals
-// (include/solver.h:446-455 fills them one task each) and walks the UNION of their adaptive trees in
-// pre-order, one interval per round:
+// a TILE of 16 consecutive pairs x one chunk of <= 16 cost-sorted omegas = 256 integrals
+// (include/solver.h:446-455 fills them one task each) and walks the UNION of their adaptive trees
+// level by level (see k_assemble_dense), one interval per round:
 //   dense round  (the interval is in the trees of >= 3 omega columns): 48 v_mfma_f64_16x16x4_f64 --
-//                 32 for K (k = 32), 16 for G (k = 16) -- fed by 16 coalesced 1-KB loads, no
+//                 32 for K (k = 32), 16 for G (k = 16; the Gauss operand is the Kronrod operand scaled
+//                 by wg/wk, so G needs no table of its own) -- fed by 16 coalesced 1-KB loads, no
 //                 per-element address or key arithmetic at all;
 //   sparse round (1-2 columns: a chain that has wandered to a damped omega refines where nobody
 //                 else does): lane = node, DPP row sums, 16 pairs of one omega at a time;
