@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "emme_device.hpp"
@@ -196,6 +197,115 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
     }
 }
 
+// Delayed ("grouped") trailing update: C(rows, cols) -= L(rows, k0 : k0+nk) * U(k0 : k0+nk, cols) for a
+// GROUP of up to GP = 4 panels (nk <= 64) in ONE pass over C -- the same MFMA sequence per element as
+// four mfma_update passes (same bits), a quarter of the reads and writes of the trailing matrix, which
+// is what a launch of 128 matrices of order 512 is bound by (1 GB of [M | M'], streamed from HBM per
+// panel: 34 GB per launch).  The multipliers are read from A (in-place LU layout) into LDS in chunks
+// of `rc` rows, GLS entries apart; the U rows (B operand) come from memory per tile and k-block.
+constexpr int GP = 4, GK = GP * NB, GLS = GK + 1;
+__device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* bb, const int* rowmap,
+                                                    double2* buf, int rc, int crow0, int nrows, int k0,
+                                                    int nk, int col0, int ncols, int tid, int wave, int lane) {
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int nct = (ncols + 15) >> 4;
+    for (int r0 = 0; r0 < nrows; r0 += rc) {
+        const int nr = min(rc, nrows - r0);
+        for (int e = tid; e < nr * GK; e += BT) {
+            const int r = e / GK, c = e % GK;
+            buf[r * GLS + c] = c < nk ? a[(size_t)rowmap[crow0 + r0 + r] * n + k0 + c] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        const int nrt = (nr + 15) >> 4;
+        for (int tile = wave; tile < nrt * nct; tile += BW) {
+            const int ct = tile / nrt, rt = tile - ct * nrt;
+            const int J = col0 + ct * 16 + i16;
+            const bool okc = J < col0 + ncols;
+            const int Jc = okc ? J : col0 + ncols - 1;
+            double2* colbase = Jc < n ? a + Jc : bb + (Jc - n);
+            double2* px[4];
+            bool okr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = rt * 16 + kq + 4 * r;
+                okr[r] = okc && rr < nr;
+                const int rcl = rr < nr ? rr : nr - 1;
+                px[r] = colbase + (size_t)rowmap[crow0 + r0 + rcl] * n;
+            }
+            d4 cre, cim;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 x = *px[r];
+                cre[r] = x.x, cim[r] = x.y;
+            }
+            const int ri = rt * 16 + i16;
+            const int ric = ri < nr ? ri : nr - 1;
+            for (int q = 0; q * NB < nk; ++q) {
+                double nare[4], aim[4], bre[4], bim[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = q * NB + 4 * ks + kq;
+                    const int kc = k < nk ? k : nk - 1;
+                    const double2 u = colbase[(size_t)rowmap[k0 + kc] * n];
+                    const bool okb = okc && k < nk;
+                    bre[ks] = okb ? u.x : 0.0, bim[ks] = okb ? u.y : 0.0;
+                    const double2 l = buf[ric * GLS + kc];
+                    const bool oka = ri < nr && k < nk;
+                    nare[ks] = oka ? -l.x : 0.0, aim[ks] = oka ? l.y : 0.0;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nare[ks], bre[ks], cre, 0, 0, 0);
+                    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nare[ks], bim[ks], cim, 0, 0, 0);
+                    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[ks], bim[ks], cre, 0, 0, 0);
+                    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[ks], bre[ks], cim, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (okr[r]) *px[r] = make_double2(cre[r], cim[r]);
+        }
+        __syncthreads();
+    }
+}
+
+// The panels of a group (first column g0, ng <= GK columns) are factored and published and their row
+// order is in the row map: apply them to columns Jlo .. Jhi-1 of [A | B] -- per panel the pivot rows
+// (T1) and the group's later pivot rows, then ONE pass over the rows below the group with all of the
+// group's multipliers.  Not inlined: the panel loop of the kernel lives on a 128-register budget of its
+// own (inlined, this costs it 230 more spilled registers).  The LDS areas are the kernel's (dynamic LDS:
+// rowmap | physrow | pivof | L11 | prow | panel).
+__device__ __noinline__ void apply_group(int n, double2* a, double2* bb, int g0, int ng, int Jlo, int Jhi) {
+    extern __shared__ double2 lds2[];
+    if (Jhi <= Jlo) return;  // uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* rowmap = reinterpret_cast<int*>(lds2);
+    double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
+    double2* panel = L11 + NB * NB + NB;
+    for (int k0 = g0; k0 < g0 + ng; k0 += NB) {
+        const int nbk = min(NB, g0 + ng - k0);
+        const int nin = g0 + ng - (k0 + nbk);  // pivot rows of the group's later panels
+        for (int e = tid; e < NB * NB; e += BT) {
+            const int kk = e / NB, c = e % NB;
+            L11[e] = (kk < nbk && c < kk) ? a[(size_t)rowmap[k0 + kk] * n + k0 + c] : make_double2(0.0, 0.0);
+        }
+        for (int e = tid; e < nin * NB; e += BT) {
+            const int r = e / NB, c = e % NB;
+            panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, Jlo, Jhi, wave, lane);
+        __syncthreads();
+        if (nin > 0) mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nin, k0, nbk, Jlo, Jhi - Jlo, wave, lane);
+        __syncthreads();
+    }
+    const int below = n - (g0 + ng);
+    if (below > 0) {
+        const int rc = max(16, (n * LS / GLS) / 16 * 16);  // rows of multipliers the panel area holds
+        mfma_update_grouped(n, a, bb, rowmap, panel, rc, g0 + ng, below, g0, ng, Jlo, Jhi - Jlo, tid, wave, lane);
+    }
+}
+
 // ---- several workgroups per matrix ---------------------------------------------------------
 // With fewer matrices than compute units a launch of one workgroup per matrix leaves CUs idle, so
 // a matrix can be given nwg = 1 + S workgroups ("roles"; role = blockIdx.x / nitems, so that every
@@ -229,6 +339,14 @@ struct SplitCtl {
     int* rowmaps;   // [nbatch][nblk][n]  (nwg > 1 only)
     double2* diag;  // [nbatch][n]
 };
+#ifdef EMME_LU_STAMPS  // diagnostic build: where the roles of a matrix spend their time (never in the product build)
+__device__ unsigned long long g_lu_stamps[32];
+#define LU_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define LU_ADD(slot, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_lu_stamps[(slot)], (t1) - (t0)); } while (0)
+#else
+#define LU_T(v)
+#define LU_ADD(slot, t0, t1)
+#endif
 constexpr int ABORT = 1 << 30;
 constexpr int SPIN_LIMIT = 16000000;  // about 4 s
 constexpr int INFO_TIMEOUT = -3;  // EMME_EDEVICE
@@ -686,6 +804,351 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     }
 }
 
+// The panel step of k_trace_solve_blocked as a function of its own (for k_trace_solve_grouped): factor the NB
+// columns from k0 on (rows in registers, pivot search, multipliers), publish U11, the new row order,
+// the multipliers (LDS panel and, in place, A) and the panel counter.  Returns 0, or LAPACK's info of an
+// exactly singular column (nothing is published then).  Not inlined, so that its register allocation is
+// its own whatever else the grouped kernel calls (inlined next to the grouped update the panel rows end up in scratch).
+__device__ __noinline__ int factor_panel(int n, double2* a, int k0, int* snap, int* flag_pub) {
+    extern __shared__ double2 lds2[];
+    __shared__ BlkShared shp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* rowmap = reinterpret_cast<int*>(lds2);
+    int* pivof = rowmap + 2 * n;
+    double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
+    double2* prow = L11 + NB * NB;
+    double2* panel = prow + NB;
+    const int nbk = min(NB, n - k0);
+    const int nrem = n - k0;
+    cd pr[NB];
+    int myrow = -1;
+    int mypiv = -1;
+    int sing_info = 0;  // (uniform: every thread makes the same reductions)
+    if (tid < nrem) {
+        myrow = rowmap[k0 + tid];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            pr[c] = c < nbk ? ldg(&a[(size_t)myrow * n + k0 + c]) : mk(0.0, 0.0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < NB; ++kk) {
+        if (kk < nbk) {  // uniform
+            // pivot search: max modulus among rows not yet used in this block.  Candidates
+            // are 64-bit keys: the modulus' bit pattern (non-negative doubles order like
+            // integers) with its 10 lowest bits replaced by 1023 - slot, so that a plain
+            // integer maximum picks the largest modulus (to 2^-42) and, among equals, the
+            // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
+            unsigned long long key = 0;
+            if (tid < nrem && mypiv < 0)
+                key = ((unsigned long long)__double_as_longlong(norm2(pr[kk])) & ~1023ull) |
+                      (unsigned long long)(1023 - tid);
+            key = wave_max(key);
+            if (lane == 0) shp.s_key[wave] = key;
+            __syncthreads();
+            key = row16_max(shp.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
+            int pt = 1023 - (int)(key & 1023ull);
+            const double bv = __longlong_as_double((long long)(key & ~1023ull));
+            if (!(bv > 0.0)) {  // exactly singular (or NaN) column
+                if (sing_info == 0) sing_info = k0 + kk + 1;
+                pt = -1;
+            }
+            if (pt >= 0) {
+                if (tid == pt) {
+                    mypiv = kk;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {
+                        // entries right of kk: the pivot row of U; left: its multipliers
+                        if (c >= kk) prow[c] = make_double2(pr[c].x, pr[c].y);
+                        else L11[kk * NB + c] = make_double2(pr[c].x, pr[c].y);
+                    }
+                }
+                __syncthreads();
+                if (tid < nrem && mypiv < 0) {
+                    const cd f = pr[kk] * rcp(mk(prow[kk].x, prow[kk].y));
+                    pr[kk] = f;  // multiplier L(row, k0+kk)
+#pragma unroll
+                    for (int c = kk + 1; c < NB; ++c)
+                        if (c < nbk) pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
+                }
+            }
+        }
+    }
+    if (sing_info != 0) return sing_info;
+
+    // ---- publish the panel: U11 -> global, new row order, multipliers -> LDS -------------
+    if (tid < nrem) {
+        pivof[tid] = mypiv;
+        if (mypiv >= 0) {
+            // this row is pivot k0+mypiv: its panel entries from column mypiv on are U
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c >= mypiv && c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
+        }
+    }
+    __syncthreads();
+    // new row order: the nbk pivots first (in pivot order), then the others, stable; the
+    // multipliers of a non-pivot row go to LDS at its NEW position (the trailing update
+    // walks rows in that order), rows LS = NB + 1 entries apart (bank spread for the
+    // 16-row operand reads of the MFMA tiles)
+    if (tid < nrem) {
+        int pos;
+        if (mypiv >= 0) {
+            pos = mypiv;
+        } else {
+            // rank among non-pivot slots = tid - #pivots before tid
+            int before = 0;
+            for (int t = 0; t < nrem; ++t) {
+                if (t >= tid) break;
+                before += pivof[t] >= 0;
+            }
+            pos = nbk + (tid - before);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                panel[(pos - nbk) * LS + c] = make_double2(pr[c].x, pr[c].y);
+        }
+        rowmap[k0 + pos] = myrow;
+    }
+    __syncthreads();
+
+    {
+        // helpers read the multipliers from A (the usual in-place LU layout: L below / left
+        // of the pivots; copied here from LDS) and the row order from a snapshot
+        const int kblk = k0 / NB;
+        if (tid < nrem) snap[(size_t)kblk * n + k0 + tid] = rowmap[k0 + tid];
+        for (int e = tid; e < NB * NB; e += BT) {
+            const int kk = e / NB, c = e % NB;
+            if (kk < nbk && c < kk) a[(size_t)rowmap[k0 + kk] * n + k0 + c] = L11[e];
+        }
+        for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+            const int r = e / NB, c = e % NB;
+            if (c < nbk) a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] = panel[r * LS + c];
+        }
+        __syncthreads();  // every thread's stores are performed; thread 0 releases them
+        if (tid == 0)  // (a maximum, not a store: an ABORT already there must survive)
+            __hip_atomic_fetch_max(flag_pub, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return 0;
+}
+
+// The truncated back substitution of k_trace_solve_blocked for columns c0 .. c1-1 (see there), as a function.
+__device__ __noinline__ void back_substitute(int n, double2* a, double2* bb, double2* diag, int c0, int c1) {
+    extern __shared__ double2 lds2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* rowmap = reinterpret_cast<const int*>(lds2);
+    double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
+    double2* panel = L11 + NB * NB + NB;
+    const int nblk = (n + NB - 1) / NB;
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * NB;
+        const int nbk = min(NB, n - k0);
+        const int live = min(c1, k0 + nbk);  // columns c0 .. live-1 of C are still needed
+        if (live <= c0) break;               // uniform
+        for (int e = tid; e < NB * NB; e += BT) {
+            const int kk = e / NB, c = e % NB;
+            double2 v = make_double2(0.0, 0.0);
+            if (kk < nbk && c < nbk && c >= kk) {
+                cd uv = ldg(&a[(size_t)rowmap[k0 + kk] * n + k0 + c]);
+                if (c == kk) uv = rcp(uv);
+                v = make_double2(uv.x, uv.y);
+            }
+            L11[e] = v;
+        }
+        for (int e = tid; e < (k0 - c0) * NB; e += BT) {  // rows c0 .. k0-1 (none if k0 <= c0)
+            const int rr = e / NB, c = e % NB;
+            panel[rr * LS + c] = c < nbk ? a[(size_t)rowmap[c0 + rr] * n + k0 + c] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        const int ncols = live - c0;
+        const int nchunks = (ncols + 63) / 64;
+        for (int q = wave; q < nchunks; q += BW) {
+            const int c = c0 + q * 64 + lane;
+            const bool okc = c < live;
+            cd x[NB];
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk)
+                x[kk] = (okc && kk < nbk) ? ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]) : mk(0.0, 0.0);
+#pragma unroll
+            for (int kk = NB - 1; kk >= 0; --kk) {
+                if (kk < nbk) {
+                    cd s = x[kk];
+#pragma unroll
+                    for (int qq = kk + 1; qq < NB; ++qq) {
+                        if (qq < nbk) {
+                            const double2 uv = L11[kk * NB + qq];
+                            s = s - mk(uv.x, uv.y) * x[qq];
+                        }
+                    }
+                    const double2 rd = L11[kk * NB + kk];
+                    s = s * mk(rd.x, rd.y);
+                    x[kk] = (k0 + kk >= c) ? s : mk(0.0, 0.0);
+                    if (okc && k0 + kk == c) diag[c] = make_double2(s.x, s.y);
+                }
+            }
+            if (okc) {
+#pragma unroll
+                for (int kk = 0; kk < NB; ++kk)
+                    if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+            }
+        }
+        __syncthreads();
+        if (k0 > c0) mfma_update<true>(n, a, bb, rowmap, panel, c0, k0 - c0, k0, nbk, n + c0, ncols, wave, lane);
+        __syncthreads();
+    }
+}
+
+// k_trace_solve_blocked<true> (no look-ahead, whole L21 panel in LDS) with the trailing matrix updated once
+// per GROUP of GP panels instead of once per panel: role 0 factors a panel (factor_panel), applies it
+// to the rest of its group's columns only, and at the end of a group puts the whole group onto A's
+// columns behind it in one pass (apply_group); the helpers wait for a whole group and do the same for
+// their columns of B.  The same operations on every element in the same order -- the same bits -- with
+// a quarter of the passes over the trailing matrix.  The kernel itself is a driver: panel, grouped
+// update and back substitution are functions with register allocations of their own.
+__global__ __launch_bounds__(BT) void k_trace_solve_grouped(int n, int nbatch, double2* A, double2* B,
+                                                            const int* active, double2* tr_out,
+                                                            int* info_out, SplitCtl ctl) {
+    extern __shared__ double2 lds2[];
+    __shared__ BlkShared sh;
+    const int role = blockIdx.x / ctl.nitems;
+    int b = blockIdx.x - role * ctl.nitems;
+    if (ctl.items) b = ctl.items[b];
+    if (active && active[b] == 0) return;
+    const int nwg = ctl.nwg, S = nwg - 1;
+    int* flag_pub = ctl.flags + 8 * b;
+    int* snap = ctl.rowmaps + (size_t)b * ((n + NB - 1) / NB) * n;
+    double2* a = A + (size_t)b * n * n;
+    double2* bb = B + (size_t)b * n * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* rowmap = reinterpret_cast<int*>(lds2);
+    double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
+    double2* panel = L11 + NB * NB + NB;
+
+    for (int r = tid; r < n; r += BT) rowmap[r] = r;
+    if (tid == 0) sh.info = 0;
+    __syncthreads();
+
+    auto abort_all = [&]() {
+        for (int q = 0; q < 8; ++q)
+            __hip_atomic_fetch_max(flag_pub + q, ABORT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wg_wait = [&](int* flag, int v) -> bool {
+        if (tid == 0) sh.go = spin_ge(flag, v, ctl.spin_limit);
+        __syncthreads();
+        const int g = sh.go;
+        __syncthreads();
+        if (g < 0) {
+            if (tid == 0) {
+                tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
+                info_out[b] = INFO_TIMEOUT;
+                abort_all();
+            }
+            return false;
+        }
+        return g < ABORT;
+    };
+    auto cut16 = [&](double frac) -> int {
+        const int c = ((int)(frac * n) + 8) / 16 * 16;
+        return c < n ? c : n;
+    };
+
+    if (role > 0) {
+        // ---- helpers: columns f0 .. f1-1 of B, a group of panels at a time ---------------------------
+        const int f0 = cut16((double)(role - 1) / S);
+        const int f1 = role == S ? n : cut16((double)role / S);
+        for (int g0 = 0; g0 < n; g0 += GK) {
+            const int ng = min(GK, n - g0);
+            const int npan = (ng + NB - 1) / NB;
+            LU_T(tw0);
+            if (!wg_wait(flag_pub, g0 / NB + npan)) return;
+            LU_T(tw1);
+            LU_ADD(16, tw0, tw1);
+            // row order after the group's last panel: position x was fixed by panel (x - g0) / NB
+            for (int x = g0 + tid; x < n; x += BT) {
+                const int pq = min(npan - 1, (x - g0) / NB);
+                rowmap[x] = snap[(size_t)(g0 / NB + pq) * n + x];
+            }
+            __syncthreads();
+            apply_group(n, a, bb, g0, ng, n + f0, n + f1);
+            LU_T(tw2);
+            LU_ADD(17, tw1, tw2);
+        }
+    } else {
+        for (int k0 = 0; k0 < n; k0 += NB) {
+            const int nbk = min(NB, n - k0);
+            LU_T(tp0);
+            const int inf = factor_panel(n, a, k0, snap, flag_pub);
+            if (inf != 0) {  // uniform
+                if (tid == 0) sh.info = inf;
+                break;
+            }
+            LU_T(tp1);
+            LU_ADD(0, tp0, tp1);
+            // the rest of this group's columns: pivot rows (T1), then the rows below (T2)
+            const int J0 = k0 + nbk;
+            const int gend = min(n, (k0 / GK) * GK + GK);
+            if (gend > J0) {
+                pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, J0, gend, wave, lane);
+                __syncthreads();
+                mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, n - k0 - nbk, k0, nbk, J0, gend - J0, wave, lane);
+                __syncthreads();
+            }
+            LU_T(tp3);
+            LU_ADD(2, tp1, tp3);
+            if (J0 == gend && gend < n) {
+                // the group is complete: its panels go onto A's columns behind it in one pass
+                const int g0 = (k0 / GK) * GK;
+                apply_group(n, a, bb, g0, gend - g0, gend, n);
+                LU_T(tp4);
+                LU_ADD(3, tp3, tp4);
+            }
+        }
+    }
+    LU_T(tb0);
+    __syncthreads();  // sh.info is visible
+    if (sh.info != 0) {  // role 0 only
+        if (tid == 0) {
+            tr_out[b] = make_double2(__builtin_nan(""), __builtin_nan(""));
+            info_out[b] = sh.info;
+            abort_all();
+        }
+        return;
+    }
+    // L^-1 P B is complete when every helper has finished its columns
+    if (role > 0) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(flag_pub + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!wg_wait(flag_pub + 1, S)) return;
+    LU_T(tb1);
+    LU_ADD(role == 0 ? 4 : 18, tb0, tb1);
+    const int c0 = role == 0 ? 0 : cut16(1.0 - cbrt(1.0 - (double)role / nwg));
+    const int c1 = role == nwg - 1 ? n : cut16(1.0 - cbrt(1.0 - (double)(role + 1) / nwg));
+    double2* diag = ctl.diag + (size_t)b * n;
+    back_substitute(n, a, bb, diag, c0, c1);
+    __syncthreads();
+    LU_T(tb2);
+    LU_ADD(role == 0 ? 5 : 19, tb0, tb2);
+    LU_ADD(role == 0 ? 6 : 20, 0ull, 1ull);
+    if (tid == 0) sh.go = __hip_atomic_fetch_add(flag_pub + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh.go != nwg - 1) return;
+    if (wave == 0) {
+        cd t = mk(0.0, 0.0);
+        for (int c = lane; c < n; c += 64) {
+            const double2 v = diag[c];
+            t = t + mk(v.x, v.y);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            t.x += __shfl_xor(t.x, off);
+            t.y += __shfl_xor(t.y, off);
+        }
+        if (lane == 0) {
+            tr_out[b] = make_double2(t.x, t.y);
+            info_out[b] = 0;
+        }
+    }
+}
+
 }  // namespace
 
 // LDS of the chunked build (560 < n <= 1024): the panel holds RC rows at a time
@@ -702,6 +1165,23 @@ size_t trace_solve_blocked_scratch(int n, int nbatch) {
     const size_t nblk = (size_t)(n + NB - 1) / NB;
     return (size_t)nbatch * (8 * sizeof(int) + nblk * n * sizeof(int) + (size_t)n * sizeof(double2)) + 256;
 }
+
+#ifdef EMME_LU_STAMPS
+static void lu_stamps_report(hipStream_t stream) {
+    if (!std::getenv("EMME_DEBUG_STAMPS")) return;
+    (void)hipStreamSynchronize(stream);
+    unsigned long long h[32] = {0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lu_stamps), sizeof h);
+    const double r0 = h[6] ? 1.0 / (100.0 * h[6]) : 0.0, r1 = h[20] ? 1.0 / (100.0 * h[20]) : 0.0;  // s_memtime: 100 MHz
+    std::fprintf(stderr, "[lu stamps, us per workgroup] role 0 (%llu): panel %.0f publish %.0f trailing %.0f group %.0f wait-helpers %.0f back+wait %.0f | "
+                 "helpers (%llu): wait %.0f apply %.0f wait-all %.0f back+wait %.0f\n", h[6], h[0] * r0, h[1] * r0, h[2] * r0, h[3] * r0, h[4] * r0, h[5] * r0,
+                 h[20], h[16] * r1, h[17] * r1, h[18] * r1, h[19] * r1);
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lu_stamps), z, sizeof z);
+}
+#else
+static void lu_stamps_report(hipStream_t) {}
+#endif
 
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
                                       double* tr, int* info, int nwg, const int* items, int nitems,
@@ -720,6 +1200,8 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         (void)hipFuncSetAttribute((const void*)k_trace_solve_blocked<true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)k_trace_solve_grouped,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_dev = cur_dev;
     }
@@ -747,6 +1229,11 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         const char* e = std::getenv("EMME_LU_SPIN_LIMIT");
         ctl.spin_limit = e ? std::max(1, std::atoi(e)) : SPIN_LIMIT;
     }
+    // grouped trailing updates (a quarter of the passes over the matrix): without look-ahead, from the
+    // order at which it pays (n = 256, 128 matrices: 1.44 -> 1.34 ms; EMME_LU_GROUP=0 switches it off, =n sets the order)
+    int group_min_n = 256;
+    if (const char* e = std::getenv("EMME_LU_GROUP")) group_min_n = std::atoi(e) <= 0 ? (1 << 30) : std::atoi(e);
+    const bool group = !chunk && nwg > 1 && ctl.na == 0 && n >= group_min_n;
     ctl.items = items;
     ctl.nitems = items ? nitems : nbatch;
     ctl.diag = (double2*)scratch;
@@ -766,27 +1253,33 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
         static thread_local size_t cap_lds = ~(size_t)0;
         static thread_local int cap_dev = -1;
         static thread_local long cap = 0;
-        static thread_local bool cap_chunk = false;
+        static thread_local int cap_chunk = -1;
+        const int variant = chunk ? 1 : group ? 2 : 0;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-        if (dev < 0 || dev != cap_dev || lds != cap_lds || chunk != cap_chunk) {
+        if (dev < 0 || dev != cap_dev || lds != cap_lds || variant != cap_chunk) {
             int per_cu = 0, ncu = 0;
-            hipError_t eo = chunk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true, true>, BT, lds)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds);
+            hipError_t eo = chunk   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true, true>, BT, lds)
+                            : group ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_grouped, BT, lds)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_solve_blocked<true>, BT, lds);
             if (dev < 0 || eo != hipSuccess ||
                 hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
                 (void)hipGetLastError();
                 per_cu = 0;
             }
-            cap = (long)per_cu * ncu, cap_dev = dev, cap_lds = lds, cap_chunk = chunk;
+            cap = (long)per_cu * ncu, cap_dev = dev, cap_lds = lds, cap_chunk = variant;
         }
         if (cap >= (long)ctl.nitems * nwg) {
             if (chunk)
                 hipLaunchKernelGGL((k_trace_solve_blocked<true, true>), dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
                                    n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+            else if (group)
+                hipLaunchKernelGGL(k_trace_solve_grouped, dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
+                                   n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
             else
                 hipLaunchKernelGGL(k_trace_solve_blocked<true>, dim3(ctl.nitems * nwg), dim3(BT), lds, stream,
                                    n, nbatch, (double2*)A, (double2*)B, active, (double2*)tr, info, ctl);
+            lu_stamps_report(stream);
             return hipGetLastError();
         }
         if (chunk) return hipErrorNotSupported;

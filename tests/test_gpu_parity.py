@@ -305,6 +305,36 @@ def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
         assert abs(trs[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, trs[b], want)
 
 
+@pytest.mark.parametrize("n,nwg", [(512, 2), (400, 2), (448, 3), (130, 2), (70, 2), (64, 2), (37, 3), (520, 2)])
+def test_trace_solve_grouped_trailing_updates_give_the_same_bits(emme, monkeypatch, n, nwg):
+    """The delayed trailing update (four panels per pass over the trailing matrix, 2-3 workgroups per
+    matrix without look-ahead; default from n = 384, forced here for every n): bit-identical to the
+    one-workgroup launch -- full and ragged groups, a group that is the whole matrix, a singular
+    neighbour -- and switched off it is the per-panel kernel again."""
+    rng = np.random.default_rng(77 * n + nwg)
+    nb = 4
+    A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    A = A + np.transpose(A, (0, 2, 1)) + 0.5 * n ** 0.5 * np.eye(n)
+    B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
+    A[2, :, (2 * n) // 3] = 0.0  # matrix 2 is exactly singular
+    with _ctx(emme, example_tokamak(npoints=16)) as ctx:
+        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        tr1, info1 = ctx.trace_solve(A, B)
+        monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
+        monkeypatch.setenv("EMME_LU_GROUP", "16")
+        trg, infog = ctx.trace_solve(A, B)
+        monkeypatch.setenv("EMME_LU_GROUP", "0")
+        tr0, info0 = ctx.trace_solve(A, B)
+    assert info1[2] == (2 * n) // 3 + 1 and np.array_equal(info1, infog) and np.array_equal(info1, info0)
+    ok = np.arange(nb) != 2
+    assert (info1[ok] == 0).all() and np.isnan(trg[2].real)
+    assert np.array_equal(tr1[ok].view(np.float64), trg[ok].view(np.float64))
+    assert np.array_equal(tr1[ok].view(np.float64), tr0[ok].view(np.float64))
+    for b in np.flatnonzero(ok):
+        want = np.trace(np.linalg.solve(A[b], B[b]))
+        assert abs(trg[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, trg[b], want)
+
+
 def test_trace_solve_chunked_panel_is_independent_of_workgroups(emme, monkeypatch):
     """n = 1024 (L21 panel in chunks of 512 rows): 2, 4, 8 and 16 workgroups per matrix give the
     same bits (with / without look-ahead, one to five A-helpers)."""
