@@ -644,6 +644,11 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                     if (e - q > best_n[k]) best_n[k] = e - q, best[k] = info[q];
                     q = e;
                 }
+                if (std::getenv("EMME_DEBUG"))
+                    for (int k = 0; k < 2; ++k)
+                        if (total[k])
+                            fprintf(stderr, "[emme] deferrals of class %d: %zu, most frequent missing interval depth %d path %llx (%zu)\n", k,
+                                    total[k], (int)(best[k] >> 56), best[k] & 0x7fffffffffffffull, best_n[k]);
                 for (int k = 0; k < 2; ++k)
                     if (total[k] >= 32 && best_n[k] * 4 >= total[k])
                         add_cache_subtree(c, L, (int)(best[k] >> 56), best[k] & 0x7fffffffffffffull, k);
