@@ -157,13 +157,11 @@ __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
         }
         const GkLane gk = gk_lane<15>(lane);
         const int sn = slotnode_of_lane(lane);
-        const cd we = mk(om.x, om.y) * ev;
         const int wm = A.wmap[wpos];
         double* blk = A.btab + ((size_t)slot * A.nchunks + (wm >> 8)) * BTAB_BLOCK;
         const int col = wm & 255;
         double2* bk = reinterpret_cast<double2*>(blk);
-        bk[tile_index(2 * sn, col)] = make_double2(gk.wk * we.x, gk.wk * we.y);
-        bk[tile_index(2 * sn + 1, col)] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
+        bk[sn * 16 + col] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
 
     }
 }
@@ -264,6 +262,8 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     for (int ks = 0; ks < 4; ++ks) grat[ks] = gauss_ratio((4 * ks + (lane >> 4)) >> 1);
     const double grat_node = gauss_ratio(col);
     const int loff = tile_index(lane >> 4, lane & 15);  // this lane's element of an MFMA operand load, k-step 0
+    const int eoff = (lane >> 5) * 16 + (lane & 15);    // the same for the phase block: node 2 ks + (rho >> 1)
+    const double2 omw = A.omega[b];                     // this lane's column omega
     // ---- the wave's 256 integrals: element r of this lane = (pair tile*16 + rho + 4 r, omega col) -----
     unsigned long long mcur[4], mnext[4];  // entries of the current / next level this element needs
     // per-element accumulators live in LDS (touched only by their owner lane, only when the element owns
@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     for (int ks = 2 * kp; ks < 2 * kp + 2; ++ks) {
                         // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[tile_index(k, p)], B[k][w] likewise:
                         // both are base + 64 ks + loff in (re, im) pairs -- ONE coalesced 1-KB load each
-                        const double2 a = a2[64 * ks + loff], bk = b2[64 * ks + loff];
+                        // (B rows 4 ks + rho belong to node 2 ks + (rho >> 1): row rho even = omega E', odd = E')
+                        const double2 a = a2[64 * ks + loff], ep = b2[32 * ks + eoff];
+                        const double2 bk = (rho & 1) ? ep : make_double2(fma(omw.x, ep.x, -(omw.y * ep.y)), fma(omw.x, ep.y, omw.y * ep.x));
                         // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
                         Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
                         Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
@@ -412,8 +414,10 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     const int c = __builtin_ctz(colmask);
                     colmask &= colmask - 1;
                     ++n_cols;
-                    const double4 kb = *reinterpret_cast<const double4*>(b2 + tile_index(2 * sn, c));  // (BK1, BK0) of the node
-                    const cd bk1 = mk(kb.x, kb.y), bk0 = mk(kb.z, kb.w);
+                    const double2 ep = b2[sn * 16 + c];  // E' of the node; BK0 = E', BK1 = omega_c E'
+                    const double wcx = __shfl(omw.x, c), wcy = __shfl(omw.y, c);
+                    const cd bk0 = mk(ep.x, ep.y);
+                    const cd bk1 = mk(fma(wcx, ep.x, -(wcy * ep.y)), fma(wcx, ep.y, wcy * ep.x));
                     const cd bg1 = grat_node * bk1, bg0 = grat_node * bk0;  // the Gauss rows: (wg / wk) times BK's
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

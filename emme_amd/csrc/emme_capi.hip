@@ -760,9 +760,35 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             }
             {
                 ScopedSpan s(c, K_ASM);
+                static const bool stamps = std::getenv("EMME_DEBUG_STAMPS") != nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                unsigned long long r0[16] = {};
+                if (stamps) {  // diagnostic (EMME_DENSE_STAMPS build): this launch's tasks, their total and longest time
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    HIP_TRY(hipMemcpy(r0, c->d_rounds, sizeof r0, hipMemcpyDeviceToHost));
+                    const unsigned long long zero = 0;
+                    HIP_TRY(hipMemcpy(c->d_rounds + 9, &zero, sizeof zero, hipMemcpyHostToDevice));
+                    HIP_TRY(hipEventCreate(&e0));
+                    HIP_TRY(hipEventCreate(&e1));
+                    HIP_TRY(hipEventRecord(e0, c->stream));
+                }
                 HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
                                               c->d_chunks, nchunks, c->d_rounds, c->stream));
+                if (stamps) {
+                    HIP_TRY(hipEventRecord(e1, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    float ms = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                    unsigned long long r1[16] = {};
+                    HIP_TRY(hipMemcpy(r1, c->d_rounds, sizeof r1, hipMemcpyDeviceToHost));
+                    const double tasks = (double)(r1[3] - r0[3]), tot = (double)(r1[8] - r0[8]);
+                    fprintf(stderr, "[emme] dense launch: %d omegas in %d chunks, %.0f tasks, %.3f ms; task ticks: mean %.0f, longest %.0f, "
+                            "sum / 2048 wave slots %.0f; rounds dense %llu sparse %llu\n", n_lane, nchunks, tasks, ms,
+                            tasks > 0 ? tot / tasks : 0.0, (double)r1[9], tot / 2048.0, r1[0] - r0[0], r1[1] - r0[1]);
+                    (void)hipEventDestroy(e0);
+                    (void)hipEventDestroy(e1);
+                }
             }
         } else if (n_lane && c->folded) {
             // phase table of this launch: exp(T omega) for every cached interval, node and omega

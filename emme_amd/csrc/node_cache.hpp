@@ -83,10 +83,12 @@ __host__ __device__ inline int slotnode_of_lane(int lane) {
     return (q & 1) ? 6 + q + neg : q - 1 + neg;
 }
 // per-launch table of weighted phases, one block per (interval slot, omega chunk of 16):
-//     BK[sn][column omega][which] as (re, im) pairs   (row k = 2 sn + which), same index map as the records:
-// rows 2 sn / 2 sn + 1 = wk (omega E) / wk E of node sn.  The embedded Gauss rule needs no table of its
-// own: its row k is (wg / wk)_k times BK's, a per-row constant that the fill applies to the A operand.
-constexpr int BTAB_BLOCK = 2 * 32 * 16;  // doubles: 8 KB
+//     E'[sn][column omega] = wk_sn exp(T_sn omega)   as (re, im) pairs, 4 KB.
+// The GEMM's B rows of node sn are 2 sn: omega E' and 2 sn + 1: E'; the fill forms the first from the second
+// in registers (the table is read by every round of every tile: half the bytes of keeping both rows).  The
+// embedded Gauss rule needs no table of its own either: its row k is (wg / wk)_k times BK's, a per-row
+// constant that the fill applies to the A operand.
+constexpr int BTAB_BLOCK = 2 * 16 * 16;  // doubles: 4 KB
 // element (row k, column / pair j) of a record or phase block, in (re, im) pairs.  The two rows of a node sit
 // side by side: the vector rounds and the cooperative kernel read a node's (Q1, Q0) as ONE 32-byte piece,
 // and the 64 lanes of an MFMA operand load (k = 4 ks + (lane >> 4), j = lane & 15) still cover 1 KB exactly.
