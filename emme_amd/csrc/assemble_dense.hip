@@ -209,8 +209,9 @@ struct DenseArgs {
 // element splits appends its two children to the next level's list.  Entries of a level are independent
 // of each other, there is no key arithmetic and no minimum search, and the accepted pieces are added
 // level by level instead of left to right (a rounding-level change, like the cooperative kernel's).
-// An element whose split does not fit the next list (more than 64 intervals of one level in a tile:
-// not met in the tests or the bench) is handed, whole, to the cooperative kernel.
+// An element whose split does not fit the next list (more than 64 intervals of one level in a tile: in
+// the bench, one strongly damped omega per search whose trees also leave the cached depth)
+// is handed, whole, to the cooperative kernel.
 __device__ __forceinline__ double fsqrt_pos(double x) {
     // sqrt for the error estimates: hardware reciprocal-square-root seed + two Newton steps (<= 1 ulp
     // for normal arguments), 0 for 0 and NaN for NaN
