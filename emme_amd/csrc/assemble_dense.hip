@@ -346,29 +346,32 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             if (dense_round) {
                 ++n_dense;
                 v4d K2re = {0.0, 0.0, 0.0, 0.0}, K2im = K2re, G2re = K2re, G2im = K2re;
-                // k-steps 0..3 feed K and G (the embedded Gauss rule lives in rows 0..15), 4..7 only K; all 20
+                // k-steps 0..3 feed K and G (the embedded Gauss rule lives in rows 0..15), 4..7 only K; all 16
                 // operand loads are issued before the first MFMA (one exposed latency per entry, not four)
+                // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[tile_index(k, p)], B[k][w] likewise:
+                // both are base + 64 ks + loff in (re, im) pairs -- ONE coalesced 1-KB load each
+                double2 av[8], ev[8];
 #pragma unroll
-                for (int kp = 0; kp < 4; ++kp) {
+                for (int ks = 0; ks < 8; ++ks) av[ks] = a2[64 * ks + loff], ev[ks] = b2[32 * ks + eoff];
+#ifndef EMME_DENSE_NO_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);  // (the loads stay ahead of the first MFMA whatever else the scheduler weighs)
+#endif
 #pragma unroll
-                    for (int ks = 2 * kp; ks < 2 * kp + 2; ++ks) {
-                        // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[tile_index(k, p)], B[k][w] likewise:
-                        // both are base + 64 ks + loff in (re, im) pairs -- ONE coalesced 1-KB load each
-                        // (B rows 4 ks + rho belong to node 2 ks + (rho >> 1): row rho even = omega E', odd = E')
-                        const double2 a = a2[64 * ks + loff], ep = b2[32 * ks + eoff];
-                        const double2 bk = (rho & 1) ? ep : make_double2(fma(omw.x, ep.x, -(omw.y * ep.y)), fma(omw.x, ep.y, omw.y * ep.x));
-                        // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
-                        Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
-                        Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
-                        K2re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, K2re, 0, 0, 0);
-                        K2im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, K2im, 0, 0, 0);
-                        if (ks < 4) {  // G = sum_k (rho_k Q[p][k]) BK[k][w]: the A operand scaled, the same B
-                            const double gx = a.x * grat[ks], gy = a.y * grat[ks];
-                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.x, Gre, 0, 0, 0);
-                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.y, Gim, 0, 0, 0);
-                            G2re = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, -bk.y, G2re, 0, 0, 0);
-                            G2im = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, bk.x, G2im, 0, 0, 0);
-                        }
+                for (int ks = 0; ks < 8; ++ks) {
+                    // (B rows 4 ks + rho belong to node 2 ks + (rho >> 1): row rho even = omega E', odd = E')
+                    const double2 a = av[ks], ep = ev[ks];
+                    const double2 bk = (rho & 1) ? ep : make_double2(fma(omw.x, ep.x, -(omw.y * ep.y)), fma(omw.x, ep.y, omw.y * ep.x));
+                    // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
+                    Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
+                    Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
+                    K2re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, K2re, 0, 0, 0);
+                    K2im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, K2im, 0, 0, 0);
+                    if (ks < 4) {  // G = sum_k (rho_k Q[p][k]) BK[k][w]: the A operand scaled, the same B
+                        const double gx = a.x * grat[ks], gy = a.y * grat[ks];
+                        Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.x, Gre, 0, 0, 0);
+                        Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.y, Gim, 0, 0, 0);
+                        G2re = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, -bk.y, G2re, 0, 0, 0);
+                        G2im = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, bk.x, G2im, 0, 0, 0);
                     }
                 }
                 Kre += K2re, Kim += K2im, Gre += G2re, Gim += G2im;
