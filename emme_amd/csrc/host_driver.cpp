@@ -32,7 +32,10 @@ namespace {
 using emme::JsonValue;
 using cplx = std::complex<double>;
 
-// ---- null vector: inverse iteration on M^H M (M complex symmetric => M^H = conj(M)) --------
+// ---- null vector: the right singular vector of the smallest singular value, by inverse iteration -------
+// (M^H M)^-1 is applied as M^-1 M^-H through ONE LU of M itself (M complex symmetric => M^-H v =
+// conj(M^-1 conj(v))): M^H M is never formed, so the factorisation sees cond(M), not its square; the
+// convergence factor per sweep is (s_n / s_n-1)^2, four sweeps.
 struct Lu {
     int n;
     std::vector<cplx> a;

@@ -150,6 +150,14 @@ def test_null_vector_matches_svd(emme):
     assert abs(abs(np.vdot(want, got)) - 1.0) < 1e-6
     assert abs(np.linalg.norm(got) - 1.0) < 1e-12
     assert np.linalg.norm(A2 @ got) <= 1e-7 * np.linalg.norm(A2)
+    # a root located to 1e-13, as the Newton search leaves it (the inverse iteration works with M's own LU,
+    # never with M^H M: the residual reaches cond-limited round-off)
+    d[-1] = 1e-13
+    A3 = (X * d) @ X.T
+    got = emme.null_vector(A3)
+    want = np.linalg.svd(A3)[2][-1].conj()
+    assert abs(abs(np.vdot(want, got)) - 1.0) < 1e-6
+    assert np.linalg.norm(A3 @ got) <= 1e-10 * np.linalg.norm(A3)
 
 
 def test_scan_generator_sequence(emme):
