@@ -204,6 +204,9 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 // panel: 34 GB per launch).  The multipliers are read from A (in-place LU layout) into LDS in chunks
 // of `rc` rows, GLS entries apart; the U rows (B operand) come from memory per tile and k-block.
 constexpr int GP = 4, GK = GP * NB, GLS = GK + 1;
+// LOWER (the truncated back substitution): only tiles on or left of the diagonal of the (rows, cols) range
+// are touched, and the group's panels are applied last to first, the order of the per-panel sweep.
+template <bool LOWER = false>
 __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* bb, const int* rowmap,
                                                     double2* buf, int rc, int crow0, int nrows, int k0,
                                                     int nk, int col0, int ncols, int tid, int wave, int lane) {
@@ -219,6 +222,7 @@ __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* 
         const int nrt = (nr + 15) >> 4;
         for (int tile = wave; tile < nrt * nct; tile += BW) {
             const int ct = tile / nrt, rt = tile - ct * nrt;
+            if (LOWER && ct > rt + (r0 >> 4)) continue;  // wave-uniform
             const int J = col0 + ct * 16 + i16;
             const bool okc = J < col0 + ncols;
             const int Jc = okc ? J : col0 + ncols - 1;
@@ -240,7 +244,9 @@ __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* 
             }
             const int ri = rt * 16 + i16;
             const int ric = ri < nr ? ri : nr - 1;
-            for (int q = 0; q * NB < nk; ++q) {
+            const int nq = (nk + NB - 1) / NB;
+            for (int qq = 0; qq < nq; ++qq) {
+                const int q = LOWER ? nq - 1 - qq : qq;
                 double nare[4], aim[4], bre[4], bim[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -302,7 +308,7 @@ __device__ __noinline__ void apply_group(int n, double2* a, double2* bb, int g0,
     const int below = n - (g0 + ng);
     if (below > 0) {
         const int rc = max(16, (n * LS / GLS) / 16 * 16);  // rows of multipliers the panel area holds
-        mfma_update_grouped(n, a, bb, rowmap, panel, rc, g0 + ng, below, g0, ng, Jlo, Jhi - Jlo, tid, wave, lane);
+        mfma_update_grouped<false>(n, a, bb, rowmap, panel, rc, g0 + ng, below, g0, ng, Jlo, Jhi - Jlo, tid, wave, lane);
     }
 }
 
@@ -930,7 +936,10 @@ __device__ __noinline__ int factor_panel(int n, double2* a, int k0, int* snap, i
     return 0;
 }
 
-// The truncated back substitution of k_trace_solve_blocked for columns c0 .. c1-1 (see there), as a function.
+// The truncated back substitution of k_trace_solve_blocked for columns c0 .. c1-1 (see there), as a function,
+// with the same grouping as the forward sweep: a block of NB rows is solved and applied to the rows above it
+// INSIDE its group of GP blocks only; the rows above the group get the whole group in one pass
+// (mfma_update_grouped<LOWER>, panels last to first: the order, and the bits, of the block-by-block sweep).
 __device__ __noinline__ void back_substitute(int n, double2* a, double2* bb, double2* diag, int c0, int c1) {
     extern __shared__ double2 lds2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -938,61 +947,78 @@ __device__ __noinline__ void back_substitute(int n, double2* a, double2* bb, dou
     double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
     double2* panel = L11 + NB * NB + NB;
     const int nblk = (n + NB - 1) / NB;
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * NB;
-        const int nbk = min(NB, n - k0);
-        const int live = min(c1, k0 + nbk);  // columns c0 .. live-1 of C are still needed
-        if (live <= c0) break;               // uniform
-        for (int e = tid; e < NB * NB; e += BT) {
-            const int kk = e / NB, c = e % NB;
-            double2 v = make_double2(0.0, 0.0);
-            if (kk < nbk && c < nbk && c >= kk) {
-                cd uv = ldg(&a[(size_t)rowmap[k0 + kk] * n + k0 + c]);
-                if (c == kk) uv = rcp(uv);
-                v = make_double2(uv.x, uv.y);
-            }
-            L11[e] = v;
-        }
-        for (int e = tid; e < (k0 - c0) * NB; e += BT) {  // rows c0 .. k0-1 (none if k0 <= c0)
-            const int rr = e / NB, c = e % NB;
-            panel[rr * LS + c] = c < nbk ? a[(size_t)rowmap[c0 + rr] * n + k0 + c] : make_double2(0.0, 0.0);
-        }
-        __syncthreads();
-        const int ncols = live - c0;
-        const int nchunks = (ncols + 63) / 64;
-        for (int q = wave; q < nchunks; q += BW) {
-            const int c = c0 + q * 64 + lane;
-            const bool okc = c < live;
-            cd x[NB];
-#pragma unroll
-            for (int kk = 0; kk < NB; ++kk)
-                x[kk] = (okc && kk < nbk) ? ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]) : mk(0.0, 0.0);
-#pragma unroll
-            for (int kk = NB - 1; kk >= 0; --kk) {
-                if (kk < nbk) {
-                    cd s = x[kk];
-#pragma unroll
-                    for (int qq = kk + 1; qq < NB; ++qq) {
-                        if (qq < nbk) {
-                            const double2 uv = L11[kk * NB + qq];
-                            s = s - mk(uv.x, uv.y) * x[qq];
-                        }
-                    }
-                    const double2 rd = L11[kk * NB + kk];
-                    s = s * mk(rd.x, rd.y);
-                    x[kk] = (k0 + kk >= c) ? s : mk(0.0, 0.0);
-                    if (okc && k0 + kk == c) diag[c] = make_double2(s.x, s.y);
+    for (int g0 = (n - 1) / GK * GK; g0 >= 0; g0 -= GK) {
+        const int ng = min(GK, n - g0);
+        if (min(c1, g0 + ng) <= c0) break;  // uniform: none of this role's columns reach down to these rows
+        const int top = max(c0, g0);        // first row of the group this role still needs
+        for (int kb = min(nblk, (g0 + ng + NB - 1) / NB) - 1; kb * NB >= g0; --kb) {
+            const int k0 = kb * NB;
+            const int nbk = min(NB, n - k0);
+            const int live = min(c1, k0 + nbk);  // columns c0 .. live-1 of C are still needed
+            if (live <= c0) break;               // uniform
+            // U11 (upper NB x NB block, with reciprocal diagonal) and the U column block above it, inside the group
+            for (int e = tid; e < NB * NB; e += BT) {
+                const int kk = e / NB, c = e % NB;
+                double2 v = make_double2(0.0, 0.0);
+                if (kk < nbk && c < nbk && c >= kk) {
+                    cd uv = ldg(&a[(size_t)rowmap[k0 + kk] * n + k0 + c]);
+                    if (c == kk) uv = rcp(uv);
+                    v = make_double2(uv.x, uv.y);
                 }
+                L11[e] = v;
             }
-            if (okc) {
+            for (int e = tid; e < (k0 - top) * NB; e += BT) {  // rows top .. k0-1 (none if k0 <= top)
+                const int rr = e / NB, c = e % NB;
+                panel[rr * LS + c] = c < nbk ? a[(size_t)rowmap[top + rr] * n + k0 + c] : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            const int ncols = live - c0;
+            const int nchunks = (ncols + 63) / 64;
+            for (int q = wave; q < nchunks; q += BW) {
+                const int c = c0 + q * 64 + lane;
+                const bool okc = c < live;
+                cd x[NB];
 #pragma unroll
                 for (int kk = 0; kk < NB; ++kk)
-                    if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+                    x[kk] = (okc && kk < nbk) ? ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]) : mk(0.0, 0.0);
+                // upper-triangular solve in registers; rows below the column index are not
+                // needed for X(c,c) and are zeroed so that they drop out of every later sum
+#pragma unroll
+                for (int kk = NB - 1; kk >= 0; --kk) {
+                    if (kk < nbk) {
+                        cd sx = x[kk];
+#pragma unroll
+                        for (int qq = kk + 1; qq < NB; ++qq) {
+                            if (qq < nbk) {
+                                const double2 uv = L11[kk * NB + qq];
+                                sx = sx - mk(uv.x, uv.y) * x[qq];
+                            }
+                        }
+                        const double2 rd = L11[kk * NB + kk];
+                        sx = sx * mk(rd.x, rd.y);
+                        x[kk] = (k0 + kk >= c) ? sx : mk(0.0, 0.0);
+                        if (okc && k0 + kk == c) diag[c] = make_double2(sx.x, sx.y);
+                    }
+                }
+                // the solved block replaces C's block rows: it is the B operand of the updates below
+                if (okc) {
+#pragma unroll
+                    for (int kk = 0; kk < NB; ++kk)
+                        if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+                }
             }
+            __syncthreads();
+            // rows above the block, inside the group: C(rr, c) -= sum_k U(rr, k0+k) X(k0+k, c), needed for rr >= c
+            // only (column tiles right of the row tile are skipped)
+            if (k0 > top)
+                mfma_update<true>(n, a, bb, rowmap, panel, top, k0 - top, k0, nbk, n + c0, ncols, wave, lane, (top - c0) / 16);
+            __syncthreads();
         }
-        __syncthreads();
-        if (k0 > c0) mfma_update<true>(n, a, bb, rowmap, panel, c0, k0 - c0, k0, nbk, n + c0, ncols, wave, lane);
-        __syncthreads();
+        // rows above the group: all of the group's blocks in one pass
+        if (g0 > c0) {
+            const int rc = max(16, (n * LS / GLS) / 16 * 16);
+            mfma_update_grouped<true>(n, a, bb, rowmap, panel, rc, c0, g0 - c0, g0, ng, n + c0, min(c1, g0) - c0, tid, wave, lane);
+        }
     }
 }
 
