@@ -12,8 +12,11 @@ rng = np.random.default_rng(2024)
 bad = 0
 total = 0
 t0 = time.time()
+# (2 and 3 workgroups per matrix at n >= 256 = the grouped kernel, k_trace_solve_grouped; the others the
+# per-panel kernel with look-ahead)
 for n, nb, splits in [(256, 128, ["2"]), (256, 64, ["4", "3"]), (256, 20, ["4", "8"]), (200, 36, ["5", "7"]),
-                      (512, 32, ["8", "6"]), (512, 64, ["4"]), (144, 50, ["5"]), (384, 24, ["8"])]:
+                      (512, 32, ["8", "6"]), (512, 64, ["4", "2", "3"]), (512, 128, ["2"]), (448, 40, ["2", "3"]),
+                      (144, 50, ["5"]), (384, 24, ["8", "2"])]:
     for r in range(reps):
         A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
         A = A + np.transpose(A, (0, 2, 1)) + 0.5 * n ** 0.5 * np.eye(n)
