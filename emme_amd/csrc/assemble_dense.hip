@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             v4d Kre = {0.0, 0.0, 0.0, 0.0}, Kim = Kre, Gre = Kre, Gim = Kre;
             const bool dense_round = __popc(colmask) >= A.dense_min_cols;
             STAMP(ts1);
+#ifdef EMME_DENSE_STAMPS
+            unsigned long long ts1x = ts1;
+#endif
             if (dense_round) {
                 ++n_dense;
                 v4d K2re = {0.0, 0.0, 0.0, 0.0}, K2im = K2re, G2re = K2re, G2im = K2re;
@@ -414,10 +417,14 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 // chain per column -- loads, shuffles through LDS, square roots -- instead of four.)
                 ++n_sparse;
                 const int sn = col;
+                unsigned long long mb[4];  // who owns the entry, per element slot
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mb[r] = __ballot(match[r]);
                 while (colmask) {
                     const int c = __builtin_ctz(colmask);
                     colmask &= colmask - 1;
                     ++n_cols;
+                    double mkx = 0.0, mky = 0.0, mgx = 0.0, mgy = 0.0;
                     const double2 ep = b2[sn * 16 + c];  // E' of the node; BK0 = E', BK1 = omega_c E'
                     const double wcx = __shfl(omw.x, c), wcy = __shfl(omw.y, c);
                     const cd bk0 = mk(ep.x, ep.y);
@@ -432,7 +439,30 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         const cd fg = q1 * bg1 + q0 * bg0;
                         const double kx = row16_sum(fk.x), ky = row16_sum(fk.y);
                         const double gx = row16_sum(fg.x), gy = row16_sum(fg.y);
-                        if (col == c) Kre[r] = kx, Kim[r] = ky, Gre[r] = gx, Gim[r] = gy;
+                        if (col == r) mkx = kx, mky = ky, mgx = gx, mgy = gy;  // (the row sums are in every lane of the row)
+                    }
+#ifdef EMME_DENSE_STAMPS
+                    {
+                        int dep;
+                        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep) : "v"(__double2loint(mkx + mgy)));
+                        const unsigned long long tsx = __builtin_amdgcn_s_memtime();
+                        cyc_sparse += tsx - ts1;
+                        ts1x = tsx;
+                    }
+#endif
+                    // the 16 elements of this column decide in ONE pass: lane (q = col < 4, rho) takes element
+                    // (pair rho + 4 q, column c), whose state is slot q of the owner lane c + 16 rho; the verdicts
+                    // go back to the owners as a ballot
+                    const int owner = c + 16 * rho;
+                    const unsigned long long mbq = col == 0 ? mb[0] : col == 1 ? mb[1] : col == 2 ? mb[2] : mb[3];
+                    int qbad = 0;
+                    bool sp = false;
+                    if (col < 4 && ((mbq >> owner) & 1ull)) sp = decide(col, owner, mkx, mky, mgx, mgy, qbad);
+                    const unsigned long long sb = __ballot(sp), bb = __ballot(qbad != 0);
+                    if (col == c) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) split[r] = ((sb >> (r + 16 * rho)) & 1ull) != 0ull;
+                        if ((bb >> (16 * rho)) & 0xfull) bad = 1;
                     }
                 }
             }
@@ -443,10 +473,12 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             }
 #endif
             STAMP(ts2);
+            if (dense_round) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (__ballot(match[r]) == 0ull) continue;  // wave-uniform
-                if (match[r]) split[r] = decide(r, lane, Kre[r], Kim[r], Gre[r], Gim[r], bad);
+                for (int r = 0; r < 4; ++r) {
+                    if (__ballot(match[r]) == 0ull) continue;  // wave-uniform
+                    if (match[r]) split[r] = decide(r, lane, Kre[r], Kim[r], Gre[r], Gim[r], bad);
+                }
             }
             if (__ballot(split[0] || split[1] || split[2] || split[3]) != 0ull) {
                 if (n_next + 2 <= 64) {
@@ -475,8 +507,8 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep2) : "v"((int)(unsigned)mnext[0]));
                 STAMP(ts3);
                 cyc_sel += ts1 - ts0;
-                if (dense_round) cyc_dense += ts2 - ts1; else cyc_sparse += ts2 - ts1;
-                cyc_dec += ts3 - ts2;
+                if (dense_round) cyc_dense += ts2 - ts1, cyc_dec += ts3 - ts2;
+                else cyc_dec += ts3 - ts1x;  // (vector rounds: the decisions start where the last column's sums ended)
             }
 #endif
         }
