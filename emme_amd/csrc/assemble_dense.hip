@@ -234,7 +234,19 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     const int ntg = (ntiles + 3) / 4;  // tile groups: 4 tiles (one per wave) per workgroup
     const int chunk = blockIdx.x / ntg;
     const int tile = (blockIdx.x - chunk * ntg) * 4 + wave;
+    // Counters leave the workgroup once: its waves add them up in LDS and the last one to finish carries the
+    // sums to memory.  (Every wave of a launch adds to the same <= 128 interval counters and four round
+    // counters: at one global atomic per lane -- 1.2 million per launch -- the launch waited for them, 10 % of
+    // its time; one more per wave cost another 3 %.)
+    __shared__ unsigned long long s_iv[16];
+    __shared__ unsigned int s_st[4];
+    __shared__ int s_arrived;
+    if (threadIdx.x < 16) s_iv[threadIdx.x] = 0ull;
+    if (threadIdx.x < 4) s_st[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_arrived = 0;
+    __syncthreads();
     if (tile >= ntiles) return;
+    const int waves_here = min(4, ntiles - (tile - wave));  // waves of this workgroup that own a tile
 
     const int2 ch = A.chunks[chunk];
     const bool has_w = col < ch.y;
@@ -536,8 +548,12 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             store(j, i, v, rdw);
         }
     }
+    // interval count of this wave's 16 pairs per omega column: the four row lanes of a column, then the
+    // workgroup's sum in LDS
+    my_intervals += __shfl_xor(my_intervals, 16);
+    my_intervals += __shfl_xor(my_intervals, 32);
     if (has_w) {
-        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
+        if (my_intervals && rho == 0) atomicAdd(&s_iv[col], my_intervals);
         if (bad) A.status[b] = 1;
     }
 #ifdef EMME_DENSE_STAMPS
@@ -550,11 +566,21 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         atomicMax(&A.stats[9], __builtin_amdgcn_s_memtime() - t_task);
     }
 #endif
-    if (A.stats && lane == 0) {
-        atomicAdd(&A.stats[0], (unsigned long long)n_dense);
-        atomicAdd(&A.stats[1], (unsigned long long)n_sparse);
-        atomicAdd(&A.stats[2], (unsigned long long)n_cols);
-        atomicAdd(&A.stats[3], 1ull);
+    if (lane == 0) {
+        atomicAdd(&s_st[0], n_dense);
+        atomicAdd(&s_st[1], n_sparse);
+        atomicAdd(&s_st[2], n_cols);
+        atomicAdd(&s_st[3], 1u);
+    }
+    __threadfence_block();
+    int arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&s_arrived, 1) + 1;  // (LDS operations of a wave are performed in order)
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived == waves_here) {
+        // the last wave of the workgroup: the sums go out (the lanes of row 0 hold the columns' items)
+        __threadfence_block();
+        if (lane < 16 && has_w && A.intervals && s_iv[lane] != 0ull) atomicAdd(&A.intervals[b], s_iv[lane]);
+        if (A.stats && lane < 4) atomicAdd(&A.stats[lane], (unsigned long long)s_st[lane]);
     }
 }
 

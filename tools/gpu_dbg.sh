@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-for v in dstamps; do
-EMME_LIB=$PWD/build/variants/$v.so EMME_DEBUG_STAMPS=1 timeout -k 10 200 python tools/iter_profile.py 1 > gpurun_out/dbg_iter.out 2> gpurun_out/dbg_iter.err
-echo "== $v"; grep "dense stamps" gpurun_out/dbg_iter.err | tail -1 | cut -c1-400
-done
-echo "== product"; timeout -k 10 100 python tools/iter_profile.py 2 2>&1 | grep "asm ms" | tail -1
+for rep in 1 2; do
+for v in default nopairs; do
+if [ $v = default ]; then unset EMME_LIB; else export EMME_LIB=$PWD/build/variants/$v.so; fi
+echo "== $v"; timeout -k 10 100 python tools/iter_profile.py 3 2>&1 | grep "asm ms\|wall" | tail -2 | tr '\n' ' '; echo
+done; done
