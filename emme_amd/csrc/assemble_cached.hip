@@ -200,6 +200,8 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
     constexpr int NODE_UNROLL = PTS == 15 ? (FOLDED ? EMME_FOLDED_UNROLL : 5) : 3;  // trips of the 3-node loop unrolled
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     extern __shared__ double lds_raw[];  // eta | g | b
+    __shared__ unsigned long long s_iv[GW];  // interval counts of the chunk's omegas (block_add_intervals)
+    if (threadIdx.x < GW) s_iv[threadIdx.x] = 0ull;
 
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
@@ -413,10 +415,8 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
         }
     }
 
-    if (has_w) {
-        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
-        if (bad) A.status[b] = 1;
-    }
+    block_add_intervals(s_iv, A.intervals, wslot, has_w, has_w && group_in_block == 0 && sub == 0, b, my_intervals);
+    if (has_w && bad) A.status[b] = 1;
 }
 
 // ---- electromagnetic fill on the shared cache layout ---------------------------------------------
@@ -437,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     constexpr int KD = 56;  // key layout: depth <= KD (>= EMME_MAX_DEPTH + 1)
     extern __shared__ double lds_raw[];  // eta | g | b | scale table
+    __shared__ unsigned long long s_iv[GW];  // interval counts of the chunk's omegas (block_add_intervals)
+    if (threadIdx.x < GW) s_iv[threadIdx.x] = 0ull;
 
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
@@ -668,10 +670,8 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
         }
     }
 
-    if (has_w) {
-        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
-        if (bad) A.status[b] = 1;
-    }
+    block_add_intervals(s_iv, A.intervals, wslot, has_w, has_w && group_in_block == 0 && sub == 0, b, my_intervals);
+    if (has_w && bad) A.status[b] = 1;
 }
 
 // ---- union walk on folded records + phase table (electrostatic, GK15) ------------------------------
@@ -713,6 +713,8 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
     constexpr int GROUPS_PER_BLOCK = 256 / GW;
     constexpr int KD = 56;
     extern __shared__ double lds_raw[];  // eta | g | b | per-group record slots
+    __shared__ unsigned long long s_iv[GW];  // interval counts of the chunk's omegas (block_add_intervals)
+    if (threadIdx.x < GW) s_iv[threadIdx.x] = 0ull;
 
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
@@ -897,10 +899,8 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
             store(j, i, v);
         }
     }
-    if (has_w) {
-        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
-        if (bad) A.status[b] = 1;
-    }
+    block_add_intervals(s_iv, A.intervals, lane, has_w, has_w && group_in_block == 0, b, my_intervals);
+    if (has_w && bad) A.status[b] = 1;
 }
 
 }  // namespace

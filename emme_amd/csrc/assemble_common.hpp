@@ -89,6 +89,23 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// Interval counters (one per batch item) leave a workgroup once per omega slot: the lanes add theirs up in
+// LDS, one designated lane per slot (`flusher`) carries the sum to memory after a barrier.  Every workgroup
+// of a fill launch adds to the same <= 128 counters: at one global atomic per lane the dense fill spent 10 %
+// of a launch waiting for them.  s_iv: LDS, one word per slot, zeroed before the kernel's
+// first barrier.
+__device__ __forceinline__ void block_add_intervals(unsigned long long* s_iv, unsigned long long* intervals,
+                                                    int slot, bool has_w, bool flusher, int b,
+                                                    unsigned long long mine) {
+    if (!intervals) return;  // (uniform)
+    if (has_w && mine) atomicAdd(&s_iv[slot], mine);
+    __syncthreads();
+    if (flusher) {
+        const unsigned long long v = s_iv[slot];
+        if (v) atomicAdd(&intervals[b], v);
+    }
+}
+
 // Adiabatic-electron closed forms kappa_e (src/Parameters.cpp:186-209).
 __device__ __forceinline__ cd kappa_e(int m, const DevParams& P, double de, double dg, cd omega) {
     if (m == 1) {

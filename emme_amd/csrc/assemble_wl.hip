@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
     constexpr int GROUPS_PER_WAVE = 64 / GW;
     constexpr int MAXD = EMME_MAX_DEPTH;
     extern __shared__ double lds_raw[];  // tables | interval stacks | node slots
+    __shared__ unsigned long long s_iv[GW];  // interval counts of the chunk's omegas (block_add_intervals)
+    if (threadIdx.x < GW) s_iv[threadIdx.x] = 0ull;
 
     const DevParams& P = A.P;
     const TransConsts TC = trans_consts();
@@ -290,10 +292,8 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
     }
 
     if (A.rounds && lane == 0 && my_rounds) atomicAdd(A.rounds, my_rounds);
-    if (has_w) {
-        if (A.intervals && my_intervals) atomicAdd(&A.intervals[b], my_intervals);
-        if (bad) A.status[b] = 1;
-    }
+    block_add_intervals(s_iv, A.intervals, lane, has_w, has_w && group_in_block == 0, b, my_intervals);
+    if (has_w && bad) A.status[b] = 1;
 }
 
 }  // namespace
