@@ -693,15 +693,17 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             // dense fill: one wave walks a (16-pair tile, chunk) serially, so (a) a chunk of omegas whose
             // trees do not overlap costs the SUM of their walks in one wave -- expensive omegas get narrow
             // chunks like in the independent-lane kernels -- and (b) a launch needs several times more
-            // tile tasks than the chip holds waves: the widest chunk shrinks until there are
+            // tile tasks than the chip holds waves: the widest chunk shrinks until there are at least
+            // EMME_DENSE_MIN_TASKS (2000; 8000 while every lane ended with a global atomic -- with the counters
+            // summed per workgroup 0 .. 3000 are equal, 44.7 ms of fill per bench search, and 8000 costs 45.8)
             int dense_cap = gw;
             if (c->tiled) {
                 const long ntiles = (c->npairs + 15) / 16;
                 const char* tt = std::getenv("EMME_DENSE_MIN_TASKS");
-                const long min_tasks = tt ? std::atol(tt) : 8000;
+                const long min_tasks = tt ? std::atol(tt) : 2000;
                 while (dense_cap > 2 && ((long)idx.size() + dense_cap - 1) / dense_cap * ntiles < min_tasks) dense_cap >>= 1;
             }
-            static const double dense_ratio = std::getenv("EMME_DENSE_COST_RATIO") ? std::atof(std::getenv("EMME_DENSE_COST_RATIO")) : 3.0;
+            static const double dense_ratio = std::getenv("EMME_DENSE_COST_RATIO") ? std::atof(std::getenv("EMME_DENSE_COST_RATIO")) : 4.0;
             size_t q = 0;
             while (q < idx.size()) {
                 int cap = c->tiled ? dense_cap : gw;
