@@ -245,3 +245,31 @@ def test_n512_full_size_assembly_against_reference_checksums(emme):
         for i, j, re, im in c["entries"]:
             assert abs(M[int(i), int(j)] - complex(re, im)) <= TOL_M * scale, (tag, i, j)
         assert np.allclose(np.abs(M).sum(axis=1)[:8], c["row_abs_sums_first8"], rtol=1e-10, atol=0)
+
+
+@pytest.mark.gpu
+def test_cfg5_n512_chains_match_reference_chains(emme):
+    """BASELINE configs[4] (N = 512, the (k_rho, omega) sweep of bench.py --config 5): four chains -- first
+    and last k_rho of the sweep, first and last guess of its lattice -- against the golden chains from the
+    reference's own kappa sources + zsysv (tests/golden/make_golden_cfg5.py): iteration counts, every
+    iterate, the roots."""
+    z = np.load(os.path.join(G, "cfg5_chains.npz"))
+    n_conv = 0
+    for kr in np.unique(z["k_rho"]):
+        sel = np.nonzero(z["k_rho"] == kr)[0]
+        d = example_tokamak(npoints=512, omega_d_coeff=1.01, k_rho=float(kr))
+        with _ctx(emme, d) as ctx:
+            roots, iters, info, its = ctx.solve_roots(z["guesses"][sel], want_iterates=True)
+        for q, b in enumerate(sel):
+            k = int(z["iters"][b])
+            want = z["iterates"][b, :k]
+            if z["converged"][b]:
+                n_conv += 1
+                assert info[q] == 0 and iters[q] == k, (kr, z["guesses"][b], info[q], iters[q], k)
+                got = its[q, :k]
+                assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), (kr, np.abs(got - want).max())
+                assert abs(roots[q] - z["roots"][b]) <= 1e-9 * abs(z["roots"][b]), (kr, roots[q], z["roots"][b])
+            else:  # the reference does not converge either: the first iterates must still agree
+                m = min(3, k)
+                assert np.abs(its[q, :m] - want[:m]).max() <= 1e-6 * np.abs(want[:m]).max()
+    assert n_conv >= 2
