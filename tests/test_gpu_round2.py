@@ -207,6 +207,20 @@ def test_stellarator_k8_fixed_work_step_by_step(emme):
             assert err.max() <= 1e-8, (n, g[b], err)
 
 
+def test_cfg4_full_size_k8_chains_match_reference_chains(emme):
+    """BASELINE configs[3] as bench.py --config 4 runs it, at FULL size: N = 256 (dim 512), electromagnetic,
+    GK31, K = 8 fixed Newton steps from two corners and the centre of the 32 x 32 guess lattice, every iterate
+    against chains from the reference's kappa sources + LAPACK zsysv (make_golden_cfg4.py)."""
+    z = np.load(os.path.join(G, "cfg4_k8_n256.npz"))
+    g, want = z["guesses"], z["iterates"]
+    with _ctx(emme, example_stellarator(npoints=256)) as ctx:
+        roots, iters, info, its = ctx.solve_roots(g, tol=0.0, step_limit=7, want_iterates=True)
+    assert (iters == 8).all() and (info == 0).all()
+    for b in range(len(g)):
+        err = np.abs(its[b, :8] - want[b]) / np.abs(want[b])
+        assert err.max() <= 1e-8, (g[b], err)
+
+
 def test_stellarator_full_size_assembly_against_reference_checksums(emme):
     """N=256 (dim 512) electromagnetic matrices at the shipped guess and at a damped omega against
     checksums of the reference's own kappa sources: every block, sampled entries, row sums."""
