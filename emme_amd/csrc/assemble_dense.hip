@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             if (!dense_round) {
                 // ---- vector round (one or two omega columns own the interval: a chain that wandered to a
                 // damped omega refines where nobody else does): lane = node (sn = lane & 15), row rho takes
-                // pair rho + 4 r; one omega column at a time, 16-lane DPP row sums; the sums land in the
-                // owner lane of each element.  (A lane = pair form with the decisions taken by 16 lanes on
-                // the LDS accumulators needs a third of the instructions and was 40 % SLOWER: one dependent
-                // chain per column -- loads, shuffles through LDS, square roots -- instead of four.)
+                // pair rho + 4 r; one omega column at a time, 16-lane DPP reductions (all four pairs at once).
+                // (A lane = pair form with the decisions taken by 16 lanes on the LDS accumulators needs a third
+                // of the instructions and was 40 % SLOWER: one dependent chain per column -- loads, shuffles
+                // through LDS, square roots -- instead of four.)
                 ++n_sparse;
                 const int sn = col;
                 unsigned long long mb[4];  // who owns the entry, per element slot
@@ -441,18 +441,30 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     const double wcx = __shfl(omw.x, c), wcy = __shfl(omw.y, c);
                     const cd bk0 = mk(ep.x, ep.y);
                     const cd bk1 = mk(fma(wcx, ep.x, -(wcy * ep.y)), fma(wcx, ep.y, wcy * ep.x));
-                    const cd bg1 = grat_node * bk1, bg0 = grat_node * bk0;  // the Gauss rows: (wg / wk) times BK's
+                    // the four pairs' node products, then ONE reduction per quantity for all four: halving
+                    // exchanges (row_mirror, row_half_mirror: a lane keeps the pairs of its side and passes the
+                    // others on), then two butterfly steps inside the quad -- 5 additions per quantity instead
+                    // of 16; lanes 4 r .. 4 r + 3 end up with the sums of pair rho + 4 r
+                    double pkx[4], pky[4], pgx[4], pgy[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int p = rho + 4 * r;  // (re-read per column from L1: a vector round rarely has two)
+                        const int p = rho + 4 * r;
                         const double4 ra = *reinterpret_cast<const double4*>(a2 + tile_index(2 * sn, p));  // (Q1, Q0): 32 bytes
                         const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);
                         const cd fk = q1 * bk1 + q0 * bk0;
-                        const cd fg = q1 * bg1 + q0 * bg0;
-                        const double kx = row16_sum(fk.x), ky = row16_sum(fk.y);
-                        const double gx = row16_sum(fg.x), gy = row16_sum(fg.y);
-                        if (col == r) mkx = kx, mky = ky, mgx = gx, mgy = gy;  // (the row sums are in every lane of the row)
+                        const cd fg = grat_node * fk;  // the Gauss rule's term of this node: (wg / wk) times the Kronrod one
+                        pkx[r] = fk.x, pky[r] = fk.y, pgx[r] = fg.x, pgy[r] = fg.y;
                     }
+                    const bool hi8 = col >= 8, sub4 = ((col >> 2) & 1) != 0;
+                    auto mv_reduce = [&](const double (&v)[4]) -> double {
+                        const double k0 = hi8 ? v[2] : v[0], k1 = hi8 ? v[3] : v[1];
+                        const double g0 = hi8 ? v[0] : v[2], g1 = hi8 ? v[1] : v[3];
+                        const double w0 = k0 + dpp_mov<0x140>(g0), w1 = k1 + dpp_mov<0x140>(g1);
+                        double x = (sub4 ? w1 : w0) + dpp_mov<0x141>(sub4 ? w0 : w1);
+                        x = dpp_add_step<0xB1>(x);
+                        return dpp_add_step<0x4E>(x);
+                    };
+                    mkx = mv_reduce(pkx), mky = mv_reduce(pky), mgx = mv_reduce(pgx), mgy = mv_reduce(pgy);
 #ifdef EMME_DENSE_STAMPS
                     {
                         int dep;
@@ -462,19 +474,22 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         ts1x = tsx;
                     }
 #endif
-                    // the 16 elements of this column decide in ONE pass: lane (q = col < 4, rho) takes element
+                    // the 16 elements of this column decide in ONE pass: lane (col = 4 q, rho) takes element
                     // (pair rho + 4 q, column c), whose state is slot q of the owner lane c + 16 rho; the verdicts
                     // go back to the owners as a ballot
                     const int owner = c + 16 * rho;
-                    const unsigned long long mbq = col == 0 ? mb[0] : col == 1 ? mb[1] : col == 2 ? mb[2] : mb[3];
+                    const int dq = col >> 2;              // the pair slot this lane's sums belong to
+                    const bool decider = (col & 3) == 0;  // (one lane of the quad decides)
+                    constexpr int DSTRIDE = 4;
+                    const unsigned long long mbq = dq == 0 ? mb[0] : dq == 1 ? mb[1] : dq == 2 ? mb[2] : mb[3];
                     int qbad = 0;
                     bool sp = false;
-                    if (col < 4 && ((mbq >> owner) & 1ull)) sp = decide(col, owner, mkx, mky, mgx, mgy, qbad);
+                    if (decider && ((mbq >> owner) & 1ull)) sp = decide(dq, owner, mkx, mky, mgx, mgy, qbad);
                     const unsigned long long sb = __ballot(sp), bb = __ballot(qbad != 0);
                     if (col == c) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) split[r] = ((sb >> (r + 16 * rho)) & 1ull) != 0ull;
-                        if ((bb >> (16 * rho)) & 0xfull) bad = 1;
+                        for (int r = 0; r < 4; ++r) split[r] = ((sb >> (DSTRIDE * r + 16 * rho)) & 1ull) != 0ull;
+                        if ((bb >> (16 * rho)) & 0xffffull) bad = 1;
                     }
                 }
             }

@@ -50,6 +50,14 @@ __device__ __forceinline__ double dpp_add_step(double v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
     return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// the value of the lane selected by the DPP control (no sum)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double row16_sum(double v) {
     v = dpp_add_step<0xB1>(v);
     v = dpp_add_step<0x4E>(v);
