@@ -438,7 +438,14 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     ++n_cols;
                     double mkx = 0.0, mky = 0.0, mgx = 0.0, mgy = 0.0;
                     const double2 ep = b2[sn * 16 + c];  // E' of the node; BK0 = E', BK1 = omega_c E'
-                    const double wcx = __shfl(omw.x, c), wcy = __shfl(omw.y, c);
+                    // (omega of column c: it lives in lane c; c is wave-uniform, so v_readlane, not a bpermute through LDS)
+                    auto lane_value = [&](double v) -> double {
+                        const long long bits = __double_as_longlong(v);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, c);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), c);
+                        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                    };
+                    const double wcx = lane_value(omw.x), wcy = lane_value(omw.y);
                     const cd bk0 = mk(ep.x, ep.y);
                     const cd bk1 = mk(fma(wcx, ep.x, -(wcy * ep.y)), fma(wcx, ep.y, wcy * ep.x));
                     // the four pairs' node products, then ONE reduction per quantity for all four: halving
@@ -451,7 +458,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         const int p = rho + 4 * r;
                         const double4 ra = *reinterpret_cast<const double4*>(a2 + tile_index(2 * sn, p));  // (Q1, Q0): 32 bytes
                         const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);
-                        const cd fk = q1 * bk1 + q0 * bk0;
+                        // fk = q1 bk1 + q0 bk0, one multiplication and three FMAs per component
+                        const cd fk = mk(fma(q1.x, bk1.x, fma(-q1.y, bk1.y, fma(q0.x, bk0.x, -(q0.y * bk0.y)))),
+                                         fma(q1.x, bk1.y, fma(q1.y, bk1.x, fma(q0.x, bk0.y, q0.y * bk0.x))));
                         const cd fg = grat_node * fk;  // the Gauss rule's term of this node: (wg / wk) times the Kronrod one
                         pkx[r] = fk.x, pky[r] = fk.y, pgx[r] = fg.x, pgy[r] = fg.y;
                     }

@@ -43,19 +43,21 @@ __device__ __forceinline__ cd times_i(cd a) { return cd{-a.y, a.x}; }
 // [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140:
 // after the four of them every lane of a 16-lane row holds the row's sum, and because
 // floating-point addition is commutative every lane holds the SAME bits.
+// (mov_dpp, not update_dpp(0, ..): every lane is written by these controls, and the "old" operand of the latter
+// cost a v_mov_b32 0 per half)
 template <int CTRL>
 __device__ __forceinline__ double dpp_add_step(double v) {
     const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
     return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // the value of the lane selected by the DPP control (no sum)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ double row16_sum(double v) {
