@@ -8,6 +8,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels_ms_per_ste
 print('$1', round(d['ms_per_step'],2), 'fill', round(k['fill_main'],2), 'deferred', round(k['fill_deferred'],2))"
 }
 run "default"
-for t in 0 500 1000 2000 3000; do EMME_DENSE_MIN_TASKS=$t run "mintasks=$t"; done
-for t in 1000 2000; do EMME_DENSE_MIN_TASKS=$t EMME_DENSE_COST_RATIO=4 run "mintasks=$t ratio=4"; done
+for c in 2 4 5 6; do EMME_DENSE_MIN_COLS=$c run "mincols=$c"; done
+for r in 3 6; do EMME_DENSE_COST_RATIO=$r run "ratio=$r"; done
+for t in 0 4000; do EMME_DENSE_MIN_TASKS=$t run "mintasks=$t"; done
 run "default"
