@@ -448,14 +448,18 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     const double wcx = lane_value(omw.x), wcy = lane_value(omw.y);
                     const cd bk0 = mk(ep.x, ep.y);
                     const cd bk1 = mk(fma(wcx, ep.x, -(wcy * ep.y)), fma(wcx, ep.y, wcy * ep.x));
-                    // the four pairs' node products, then ONE reduction per quantity for all four: halving
-                    // exchanges (row_mirror, row_half_mirror: a lane keeps the pairs of its side and passes the
-                    // others on), then two butterfly steps inside the quad -- 5 additions per quantity instead
-                    // of 16; lanes 4 r .. 4 r + 3 end up with the sums of pair rho + 4 r
+                    // the four pairs' node products, then ONE reduction per quantity for all four: two halving
+                    // exchanges (row_mirror, row_half_mirror: a lane keeps half of what it holds and adds the
+                    // partner's copy of it), then two butterfly steps inside the quad -- 5 additions per quantity
+                    // instead of 16.  The lane takes its pairs in the order r ^ m, m = 2 (lane >= 8) + (lane / 4 odd),
+                    // so that what it keeps is always its slots 0, 1 (then 0) and what the partner wants its slots
+                    // 3, 2 (row_mirror flips both bits of m; then slot 1: row_half_mirror flips the low one): no
+                    // selects.  Lanes 4 q .. 4 q + 3 end up with the sums of pair rho + 4 q.
+                    const int pmask = (col >= 8 ? 2 : 0) | ((col >> 2) & 1);
                     double pkx[4], pky[4], pgx[4], pgy[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int p = rho + 4 * r;
+                        const int p = rho + 4 * (r ^ pmask);
                         const double4 ra = *reinterpret_cast<const double4*>(a2 + tile_index(2 * sn, p));  // (Q1, Q0): 32 bytes
                         const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);
                         // fk = q1 bk1 + q0 bk0, one multiplication and three FMAs per component
@@ -464,12 +468,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         const cd fg = grat_node * fk;  // the Gauss rule's term of this node: (wg / wk) times the Kronrod one
                         pkx[r] = fk.x, pky[r] = fk.y, pgx[r] = fg.x, pgy[r] = fg.y;
                     }
-                    const bool hi8 = col >= 8, sub4 = ((col >> 2) & 1) != 0;
                     auto mv_reduce = [&](const double (&v)[4]) -> double {
-                        const double k0 = hi8 ? v[2] : v[0], k1 = hi8 ? v[3] : v[1];
-                        const double g0 = hi8 ? v[0] : v[2], g1 = hi8 ? v[1] : v[3];
-                        const double w0 = k0 + dpp_mov<0x140>(g0), w1 = k1 + dpp_mov<0x140>(g1);
-                        double x = (sub4 ? w1 : w0) + dpp_mov<0x141>(sub4 ? w0 : w1);
+                        const double w0 = v[0] + dpp_mov<0x140>(v[3]), w1 = v[1] + dpp_mov<0x140>(v[2]);
+                        double x = w0 + dpp_mov<0x141>(w1);
                         x = dpp_add_step<0xB1>(x);
                         return dpp_add_step<0x4E>(x);
                     };
