@@ -48,8 +48,9 @@ __device__ __forceinline__ void stg(double2* p, cd v) { *p = make_double2(v.x, v
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
     const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, false);
+    // (mov_dpp: every lane is written by these controls; update_dpp's "old" operand cost a v_mov_b32 0 per half)
+    const unsigned olo = (unsigned)__builtin_amdgcn_mov_dpp((int)lo, CTRL, 0xf, 0xf, true);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_mov_dpp((int)hi, CTRL, 0xf, 0xf, true);
     const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
     return o > v ? o : v;
 }
@@ -275,13 +276,28 @@ __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* 
     }
 }
 
+// Arguments of a __noinline__ device function arrive in vector registers: the compiler must take them for
+// per-lane values and turns every branch and address that depends on them into exec-mask code (380
+// s_and_saveexec in factor_panel alone).  They are wave-uniform here: say so.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uniform(T* p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
 // The panels of a group (first column g0, ng <= GK columns) are factored and published and their row
 // order is in the row map: apply them to columns Jlo .. Jhi-1 of [A | B] -- per panel the pivot rows
 // (T1) and the group's later pivot rows, then ONE pass over the rows below the group with all of the
 // group's multipliers.  Not inlined: the panel loop of the kernel lives on a 128-register budget of its
 // own (inlined, this costs it 230 more spilled registers).  The LDS areas are the kernel's (dynamic LDS:
 // rowmap | physrow | pivof | L11 | prow | panel).
-__device__ __noinline__ void apply_group(int n, double2* a, double2* bb, int g0, int ng, int Jlo, int Jhi) {
+__device__ __noinline__ void apply_group(int n_, double2* a_, double2* bb_, int g0_, int ng_, int Jlo_, int Jhi_) {
+    const int n = uniform(n_), g0 = uniform(g0_), ng = uniform(ng_), Jlo = uniform(Jlo_), Jhi = uniform(Jhi_);
+    double2* a = uniform(a_);
+    double2* bb = uniform(bb_);
     extern __shared__ double2 lds2[];
     if (Jhi <= Jlo) return;  // uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -815,7 +831,11 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
 // the multipliers (LDS panel and, in place, A) and the panel counter.  Returns 0, or LAPACK's info of an
 // exactly singular column (nothing is published then).  Not inlined, so that its register allocation is
 // its own whatever else the grouped kernel calls (inlined next to the grouped update the panel rows end up in scratch).
-__device__ __noinline__ int factor_panel(int n, double2* a, int k0, int* snap, int* flag_pub) {
+__device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap_, int* flag_pub_) {
+    const int n = uniform(n_), k0 = uniform(k0_);
+    double2* a = uniform(a_);
+    int* snap = uniform(snap_);
+    int* flag_pub = uniform(flag_pub_);
     extern __shared__ double2 lds2[];
     __shared__ BlkShared shp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -940,7 +960,11 @@ __device__ __noinline__ int factor_panel(int n, double2* a, int k0, int* snap, i
 // with the same grouping as the forward sweep: a block of NB rows is solved and applied to the rows above it
 // INSIDE its group of GP blocks only; the rows above the group get the whole group in one pass
 // (mfma_update_grouped<LOWER>, panels last to first: the order, and the bits, of the block-by-block sweep).
-__device__ __noinline__ void back_substitute(int n, double2* a, double2* bb, double2* diag, int c0, int c1) {
+__device__ __noinline__ void back_substitute(int n_, double2* a_, double2* bb_, double2* diag_, int c0_, int c1_) {
+    const int n = uniform(n_), c0 = uniform(c0_), c1 = uniform(c1_);
+    double2* a = uniform(a_);
+    double2* bb = uniform(bb_);
+    double2* diag = uniform(diag_);
     extern __shared__ double2 lds2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* rowmap = reinterpret_cast<const int*>(lds2);
