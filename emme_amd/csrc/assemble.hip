@@ -358,7 +358,11 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     __shared__ int s_bad;
 
     const DevParams& P = A.P;
+#ifdef EMME_COOP_SREG_CONSTS
     const TransConsts TC = trans_consts();
+#else
+    const TransConsts TC = trans_consts_v();  // (vector registers: see trans_consts_v)
+#endif
     const int N = P.N, dim = P.dim;
     for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_tab[k] = A.tab[k];
     if (threadIdx.x == 0) s_bad = 0;

@@ -197,6 +197,20 @@ __device__ __forceinline__ TransConsts trans_consts() {
     k.e3 = sreg(1.6666666666666666e-01);
     return k;
 }
+// The same coefficients pinned in VECTOR registers: for a kernel that has registers to spare but runs out
+// of scalar ones (the cooperative kernel: 124 spilled SGPRs, every eighth instruction a v_readlane /
+// v_writelane of the spill lanes, with the coefficients in scalar registers).
+__device__ __forceinline__ double vreg(double c) {
+    asm("" : "+v"(c));
+    return c;
+}
+__device__ __forceinline__ TransConsts trans_consts_v() {
+    TransConsts k = trans_consts();
+    double* f = reinterpret_cast<double*>(&k);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(TransConsts) / sizeof(double)); ++i) f[i] = vreg(f[i]);
+    return k;
+}
 __device__ __forceinline__ void fsincos(double x, double& s, double& c, const TransConsts& k) {
     // two-term reduction: the third term of pi/2 (1.5e-33 n) is below 1e-17 for |n| < 6e15
     const double n = rint(x * k.two_over_pi);
