@@ -43,40 +43,44 @@ __device__ __forceinline__ cd ldg(const double2* p) {
 }
 __device__ __forceinline__ void stg(double2* p, cd v) { *p = make_double2(v.x, v.y); }
 
-// max over the 16 lanes of a DPP row, result in every lane of the row (no LDS traffic):
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+// max over the 16 lanes of a DPP row, result in every lane of the row (no LDS traffic): quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror; 32-bit keys (the pivot search): one v_max_u32 with a DPP
+// operand per step
 template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
-    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    // (mov_dpp: every lane is written by these controls; update_dpp's "old" operand cost a v_mov_b32 0 per half)
-    const unsigned olo = (unsigned)__builtin_amdgcn_mov_dpp((int)lo, CTRL, 0xf, 0xf, true);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_mov_dpp((int)hi, CTRL, 0xf, 0xf, true);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+__device__ __forceinline__ unsigned int dpp_max32_step(unsigned int v) {
+    const unsigned int o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
     return o > v ? o : v;
 }
-__device__ __forceinline__ unsigned long long row16_max(unsigned long long v) {
-    v = dpp_max_step<0xB1>(v);
-    v = dpp_max_step<0x4E>(v);
-    v = dpp_max_step<0x141>(v);
-    v = dpp_max_step<0x140>(v);
+__device__ __forceinline__ unsigned int row16_max32(unsigned int v) {
+    v = dpp_max32_step<0xB1>(v);
+    v = dpp_max32_step<0x4E>(v);
+    v = dpp_max32_step<0x141>(v);
+    v = dpp_max32_step<0x140>(v);
     return v;
 }
-// max over the whole wave, in every lane
-__device__ __forceinline__ unsigned long long wave_max(unsigned long long v) {
-    v = row16_max(v);
-    unsigned long long m = 0;
+__device__ __forceinline__ unsigned int wave_max32(unsigned int v) {
+    v = row16_max32(v);
+    unsigned int m = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * r);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * r);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        const unsigned int o = (unsigned)__builtin_amdgcn_readlane((int)v, 16 * r);
         m = o > m ? o : m;
     }
     return m;
 }
+// pivot candidate of a row: the high word of |x|^2 (sign 0, 11 exponent and 10 mantissa bits: the modulus to
+// 2^-11) with its 10 lowest bits replaced by 1023 - slot, so that a plain 32-bit maximum picks the largest
+// modulus and, among equals, the first row.  0 = not a candidate / exactly zero; an |x|^2 below 2^-1012 counts
+// as zero, a NaN or infinity as the largest (and is then reported as a singular column).
+__device__ __forceinline__ unsigned int pivot_key(double n2, int slot) {
+    const unsigned int hi = (unsigned int)__double2hiint(n2);
+    return (hi & ~1023u) ? ((hi & ~1023u) | (unsigned int)(1023 - slot)) : 0u;
+}
+// the candidate that won: usable as a pivot? (positive, finite)
+__device__ __forceinline__ bool pivot_ok(unsigned int key) { return key != 0u && key < 0x7ff00000u; }
 
 struct BlkShared {
-    unsigned long long s_key[BW];  // per-wave pivot candidates
+    unsigned int s_key[BW];  // per-wave pivot candidates
     double s_val[BW];
     int s_idx[BW];
     int info;
@@ -548,17 +552,14 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                 // integers) with its 10 lowest bits replaced by 1023 - slot, so that a plain
                 // integer maximum picks the largest modulus (to 2^-42) and, among equals, the
                 // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
-                unsigned long long key = 0;
-                if (tid < nrem && mypiv < 0)
-                    key = ((unsigned long long)__double_as_longlong(norm2(pr[kk])) & ~1023ull) |
-                          (unsigned long long)(1023 - tid);
-                key = wave_max(key);
+                unsigned int key = 0;
+                if (tid < nrem && mypiv < 0) key = pivot_key(norm2(pr[kk]), tid);
+                key = wave_max32(key);
                 if (lane == 0) sh.s_key[wave] = key;
                 __syncthreads();
-                key = row16_max(sh.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
-                int pt = 1023 - (int)(key & 1023ull);
-                const double bv = __longlong_as_double((long long)(key & ~1023ull));
-                if (!(bv > 0.0)) {  // exactly singular (or NaN) column
+                key = row16_max32(sh.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
+                int pt = 1023 - (int)(key & 1023u);
+                if (!pivot_ok(key)) {  // exactly singular (or NaN) column
                     if (tid == 0 && !singular) sh.info = k0 + kk + 1;
                     singular = true;
                     pt = -1;
@@ -864,17 +865,14 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
             // integers) with its 10 lowest bits replaced by 1023 - slot, so that a plain
             // integer maximum picks the largest modulus (to 2^-42) and, among equals, the
             // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
-            unsigned long long key = 0;
-            if (tid < nrem && mypiv < 0)
-                key = ((unsigned long long)__double_as_longlong(norm2(pr[kk])) & ~1023ull) |
-                      (unsigned long long)(1023 - tid);
-            key = wave_max(key);
+            unsigned int key = 0;
+            if (tid < nrem && mypiv < 0) key = pivot_key(norm2(pr[kk]), tid);
+            key = wave_max32(key);
             if (lane == 0) shp.s_key[wave] = key;
             __syncthreads();
-            key = row16_max(shp.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
-            int pt = 1023 - (int)(key & 1023ull);
-            const double bv = __longlong_as_double((long long)(key & ~1023ull));
-            if (!(bv > 0.0)) {  // exactly singular (or NaN) column
+            key = row16_max32(shp.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
+            int pt = 1023 - (int)(key & 1023u);
+            if (!pivot_ok(key)) {  // exactly singular (or NaN) column
                 if (sing_info == 0) sing_info = k0 + kk + 1;
                 pt = -1;
             }
