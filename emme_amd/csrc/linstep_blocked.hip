@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned int pivot_key(double n2, int slot) {
 __device__ __forceinline__ bool pivot_ok(unsigned int key) { return key != 0u && key < 0x7ff00000u; }
 
 struct BlkShared {
-    unsigned int s_key[BW];  // per-wave pivot candidates
+    unsigned int s_key[2][BW];  // per-wave pivot candidates (columns alternate: one barrier per column)
     double s_val[BW];
     int s_idx[BW];
     int info;
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     int* physrow = rowmap + n;                   // remaining-row slot t -> physical row
     int* pivof = physrow + n;                    // slot t -> pivot index in this block or -1
     double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
-    double2* prow = L11 + NB * NB;
-    double2* panel = prow + NB;
+    double2* panel = L11 + NB * NB + NB;
+    double2* cand = panel;  // [2][BW][NB] candidate pivot rows of the panel loop (the area is free during it)
 
     for (int r = tid; r < n; r += BT) rowmap[r] = r;
     if (tid == 0) sh.info = 0;
@@ -540,9 +540,14 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         bool singular = false;
         if (tid < nrem) {
             myrow = rowmap[k0 + tid];
+            if (nbk == NB) {  // (uniform; one batch of loads instead of a test per column)
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
-                pr[c] = c < nbk ? ldg(&a[(size_t)myrow * n + k0 + c]) : mk(0.0, 0.0);
+                for (int c = 0; c < NB; ++c) pr[c] = ldg(&a[(size_t)myrow * n + k0 + c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    pr[c] = c < nbk ? ldg(&a[(size_t)myrow * n + k0 + c]) : mk(0.0, 0.0);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < NB; ++kk) {
@@ -554,10 +559,17 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                 // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
                 unsigned int key = 0;
                 if (tid < nrem && mypiv < 0) key = pivot_key(norm2(pr[kk]), tid);
-                key = wave_max32(key);
-                if (lane == 0) sh.s_key[wave] = key;
+                const unsigned int wkey = wave_max32(key);
+                // ONE barrier per column: every wave's candidate row goes to LDS with its key (keys carry
+                // the slot: one lane per wave matches), and the winner's is read back from its wave's place
+                double2* cw = cand + ((kk & 1) * BW + wave) * NB;
+                if (key == wkey && key != 0u) {
+#pragma unroll
+                    for (int c = kk; c < NB; ++c) cw[c] = make_double2(pr[c].x, pr[c].y);
+                }
+                if (lane == 0) sh.s_key[kk & 1][wave] = wkey;
                 __syncthreads();
-                key = row16_max32(sh.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
+                key = row16_max32(sh.s_key[kk & 1][lane & 15]);  // BW = 16 waves: one candidate per lane
                 int pt = 1023 - (int)(key & 1023u);
                 if (!pivot_ok(key)) {  // exactly singular (or NaN) column
                     if (tid == 0 && !singular) sh.info = k0 + kk + 1;
@@ -565,22 +577,19 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                     pt = -1;
                 }
                 if (pt >= 0) {
+                    const double2* prow = cand + ((kk & 1) * BW + (pt >> 6)) * NB;
                     if (tid == pt) {
                         mypiv = kk;
 #pragma unroll
-                        for (int c = 0; c < NB; ++c) {
-                            // entries right of kk: the pivot row of U; left: its multipliers
-                            if (c >= kk) prow[c] = make_double2(pr[c].x, pr[c].y);
-                            else L11[kk * NB + c] = make_double2(pr[c].x, pr[c].y);
-                        }
+                        for (int c = 0; c < kk; ++c)  // left of kk: the pivot row's multipliers
+                            L11[kk * NB + c] = make_double2(pr[c].x, pr[c].y);
                     }
-                    __syncthreads();
                     if (tid < nrem && mypiv < 0) {
                         const cd f = pr[kk] * rcp(mk(prow[kk].x, prow[kk].y));
                         pr[kk] = f;  // multiplier L(row, k0+kk)
 #pragma unroll
-                        for (int c = kk + 1; c < NB; ++c)
-                            if (c < nbk) pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
+                        for (int c = kk + 1; c < NB; ++c)  // (columns >= nbk of a short last panel hold zeros: no test)
+                            pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
                     }
                 }
             }
@@ -588,6 +597,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         if (singular) break;  // uniform: every thread made the same reduction
 
         // ---- publish the panel: U11 -> global, new row order, multipliers -> LDS -------------
+        // (pivots per wave, for the ranks below)
+        const unsigned long long pbal = __ballot(tid < nrem && mypiv >= 0);
+        if ((tid & 63) == 0) sh.s_idx[tid >> 6] = __popcll(pbal);
         if (tid < nrem) {
             pivof[tid] = mypiv;
             if (mypiv >= 0) {
@@ -607,12 +619,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             if (mypiv >= 0) {
                 pos = mypiv;
             } else {
-                // rank among non-pivot slots = tid - #pivots before tid
-                int before = 0;
-                for (int t = 0; t < nrem; ++t) {
-                    if (t >= tid) break;
-                    before += pivof[t] >= 0;
-                }
+                // rank among non-pivot slots = tid - #pivots before tid (lower waves' counts + this wave's lanes below)
+                int before = __popcll(pbal & ((1ull << (tid & 63)) - 1ull));
+                for (int w = 0; w < (tid >> 6); ++w) before += sh.s_idx[w];
                 pos = nbk + (tid - before);
                 if (CHUNK) {  // straight to A: the panel does not fit in LDS
 #pragma unroll
@@ -843,20 +852,31 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
     int* rowmap = reinterpret_cast<int*>(lds2);
     int* pivof = rowmap + 2 * n;
     double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
-    double2* prow = L11 + NB * NB;
-    double2* panel = prow + NB;
+    double2* panel = L11 + NB * NB + NB;
+    double2* cand = panel;  // [2][BW][NB] candidate pivot rows: the panel area is free until the multipliers go there
     const int nbk = min(NB, n - k0);
     const int nrem = n - k0;
     cd pr[NB];
     int myrow = -1;
     int mypiv = -1;
     int sing_info = 0;  // (uniform: every thread makes the same reductions)
+    LU_T(tf0);
     if (tid < nrem) {
         myrow = rowmap[k0 + tid];
+        if (nbk == NB) {  // (uniform; one batch of loads instead of a test per column)
 #pragma unroll
-        for (int c = 0; c < NB; ++c)
-            pr[c] = c < nbk ? ldg(&a[(size_t)myrow * n + k0 + c]) : mk(0.0, 0.0);
+            for (int c = 0; c < NB; ++c) pr[c] = ldg(&a[(size_t)myrow * n + k0 + c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                pr[c] = c < nbk ? ldg(&a[(size_t)myrow * n + k0 + c]) : mk(0.0, 0.0);
+        }
     }
+#ifdef EMME_LU_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    LU_T(tf1);
+    LU_ADD(8, tf0, tf1);
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
         if (kk < nbk) {  // uniform
@@ -867,39 +887,47 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
             // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
             unsigned int key = 0;
             if (tid < nrem && mypiv < 0) key = pivot_key(norm2(pr[kk]), tid);
-            key = wave_max32(key);
-            if (lane == 0) shp.s_key[wave] = key;
+            const unsigned int wkey = wave_max32(key);
+            // ONE barrier per column: every wave's candidate row goes to LDS with its key (see the kernel)
+            double2* cw = cand + ((kk & 1) * BW + wave) * NB;
+            if (key == wkey && key != 0u) {
+#pragma unroll
+                for (int c = kk; c < NB; ++c) cw[c] = make_double2(pr[c].x, pr[c].y);
+            }
+            if (lane == 0) shp.s_key[kk & 1][wave] = wkey;
             __syncthreads();
-            key = row16_max32(shp.s_key[lane & 15]);  // BW = 16 waves: one candidate per lane
+            key = row16_max32(shp.s_key[kk & 1][lane & 15]);  // BW = 16 waves: one candidate per lane
             int pt = 1023 - (int)(key & 1023u);
             if (!pivot_ok(key)) {  // exactly singular (or NaN) column
                 if (sing_info == 0) sing_info = k0 + kk + 1;
                 pt = -1;
             }
             if (pt >= 0) {
+                const double2* prow = cand + ((kk & 1) * BW + (pt >> 6)) * NB;
                 if (tid == pt) {
                     mypiv = kk;
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {
-                        // entries right of kk: the pivot row of U; left: its multipliers
-                        if (c >= kk) prow[c] = make_double2(pr[c].x, pr[c].y);
-                        else L11[kk * NB + c] = make_double2(pr[c].x, pr[c].y);
-                    }
+                    for (int c = 0; c < kk; ++c)  // left of kk: the pivot row's multipliers
+                        L11[kk * NB + c] = make_double2(pr[c].x, pr[c].y);
                 }
-                __syncthreads();
                 if (tid < nrem && mypiv < 0) {
                     const cd f = pr[kk] * rcp(mk(prow[kk].x, prow[kk].y));
                     pr[kk] = f;  // multiplier L(row, k0+kk)
 #pragma unroll
-                    for (int c = kk + 1; c < NB; ++c)
-                        if (c < nbk) pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
+                    for (int c = kk + 1; c < NB; ++c)  // (columns >= nbk of a short last panel hold zeros: no test)
+                        pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
                 }
             }
         }
     }
     if (sing_info != 0) return sing_info;
+    LU_T(tf2);
+    LU_ADD(9, tf1, tf2);
 
     // ---- publish the panel: U11 -> global, new row order, multipliers -> LDS -------------
+    // (pivots per wave, for the ranks below)
+    const unsigned long long pbal = __ballot(tid < nrem && mypiv >= 0);
+    if (lane == 0) shp.s_idx[wave] = __popcll(pbal);
     if (tid < nrem) {
         pivof[tid] = mypiv;
         if (mypiv >= 0) {
@@ -919,12 +947,9 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
         if (mypiv >= 0) {
             pos = mypiv;
         } else {
-            // rank among non-pivot slots = tid - #pivots before tid
-            int before = 0;
-            for (int t = 0; t < nrem; ++t) {
-                if (t >= tid) break;
-                before += pivof[t] >= 0;
-            }
+            // rank among non-pivot slots = tid - #pivots before tid (lower waves' counts + this wave's lanes below)
+            int before = __popcll(pbal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) before += shp.s_idx[w];
             pos = nbk + (tid - before);
 #pragma unroll
             for (int c = 0; c < NB; ++c)
@@ -933,6 +958,8 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
         rowmap[k0 + pos] = myrow;
     }
     __syncthreads();
+    LU_T(tf3);
+    LU_ADD(10, tf2, tf3);
 
     {
         // helpers read the multipliers from A (the usual in-place LU layout: L below / left
@@ -951,6 +978,8 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
         if (tid == 0)  // (a maximum, not a store: an ABORT already there must survive)
             __hip_atomic_fetch_max(flag_pub, kblk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    LU_T(tf4);
+    LU_ADD(11, tf3, tf4);
     return 0;
 }
 
@@ -1202,11 +1231,11 @@ __global__ __launch_bounds__(BT) void k_trace_solve_grouped(int n, int nbatch, d
 // LDS of the chunked build (560 < n <= 1024): the panel holds RC rows at a time
 size_t trace_solve_chunked_lds(int n) {
     const int rows = n < RC ? n : RC;
-    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)rows * LS) * sizeof(double2);
+    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + std::max((size_t)rows * LS, (size_t)2 * BW * NB)) * sizeof(double2);
 }
 
 size_t trace_solve_blocked_lds(int n) {
-    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + (size_t)n * LS) * sizeof(double2);
+    return (((size_t)3 * n * sizeof(int) + 15) / 16 + NB * NB + NB + std::max((size_t)n * LS, (size_t)2 * BW * NB)) * sizeof(double2);
 }
 
 size_t trace_solve_blocked_scratch(int n, int nbatch) {
@@ -1224,6 +1253,8 @@ static void lu_stamps_report(hipStream_t stream) {
     std::fprintf(stderr, "[lu stamps, us per workgroup] role 0 (%llu): panel %.0f publish %.0f trailing %.0f group %.0f wait-helpers %.0f back+wait %.0f | "
                  "helpers (%llu): wait %.0f apply %.0f wait-all %.0f back+wait %.0f\n", h[6], h[0] * r0, h[1] * r0, h[2] * r0, h[3] * r0, h[4] * r0, h[5] * r0,
                  h[20], h[16] * r1, h[17] * r1, h[18] * r1, h[19] * r1);
+    std::fprintf(stderr, "[lu stamps] panel: load rows %.0f columns %.0f rank + multipliers to LDS %.0f copy to A + release %.0f\n", h[8] * r0, h[9] * r0,
+                 h[10] * r0, h[11] * r0);
     unsigned long long z[32] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lu_stamps), z, sizeof z);
 }
