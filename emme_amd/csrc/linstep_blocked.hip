@@ -68,6 +68,11 @@ __device__ __forceinline__ unsigned int wave_max32(unsigned int v) {
     }
     return m;
 }
+// acc - f p with four fused multiply-adds (the panels' rank-1 updates; the trailing updates accumulate fused
+// products on the matrix cores anyway)
+__device__ __forceinline__ cd cmsub(cd acc, cd f, double2 p) {
+    return cd{__builtin_fma(f.y, p.y, __builtin_fma(-f.x, p.x, acc.x)), __builtin_fma(-f.y, p.x, __builtin_fma(-f.x, p.y, acc.y))};
+}
 // pivot candidate of a row: the high word of |x|^2 (sign 0, 11 exponent and 10 mantissa bits: the modulus to
 // 2^-11) with its 10 lowest bits replaced by 1023 - slot, so that a plain 32-bit maximum picks the largest
 // modulus and, among equals, the first row.  0 = not a candidate / exactly zero; an |x|^2 below 2^-1012 counts
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
                         pr[kk] = f;  // multiplier L(row, k0+kk)
 #pragma unroll
                         for (int c = kk + 1; c < NB; ++c)  // (columns >= nbk of a short last panel hold zeros: no test)
-                            pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
+                            pr[c] = cmsub(pr[c], f, prow[c]);
                     }
                 }
             }
@@ -915,7 +920,7 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
                     pr[kk] = f;  // multiplier L(row, k0+kk)
 #pragma unroll
                     for (int c = kk + 1; c < NB; ++c)  // (columns >= nbk of a short last panel hold zeros: no test)
-                        pr[c] = pr[c] - f * mk(prow[c].x, prow[c].y);
+                        pr[c] = cmsub(pr[c], f, prow[c]);
                 }
             }
         }
