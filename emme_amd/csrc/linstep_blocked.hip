@@ -73,6 +73,41 @@ __device__ __forceinline__ unsigned int wave_max32(unsigned int v) {
 __device__ __forceinline__ cd cmsub(cd acc, cd f, double2 p) {
     return cd{__builtin_fma(f.y, p.y, __builtin_fma(-f.x, p.x, acc.x)), __builtin_fma(-f.y, p.x, __builtin_fma(-f.x, p.y, acc.y))};
 }
+#ifndef EMME_LU_SOLVE_BATCH
+#define EMME_LU_SOLVE_BATCH 4
+#endif
+constexpr int SOLVE_BATCH = EMME_LU_SOLVE_BATCH;  // (a power of two)
+// Unit-lower solve with L11 (T1: the NB pivot rows of one column, in registers).  The uniform test per row
+// also keeps the LDS reads of one row together and the rows apart (all 120 hoisted do not fit in registers).
+__device__ __forceinline__ void t1_solve(cd (&u)[NB], const double2* L11, int nbk) {
+#pragma unroll
+    for (int kk = 1; kk < NB; ++kk) {
+        if (kk < nbk) {
+#pragma unroll
+            for (int c = 0; c < kk; ++c) u[kk] = cmsub(u[kk], u[c], L11[kk * NB + c]);
+        }
+    }
+}
+// Upper-triangular solve of one column of the truncated back substitution against the LDS copy of U11
+// (reciprocal diagonal; zero outside the block's nbk x nbk triangle, so that a short last block needs no
+// test: its extra rows stay zero).  Rows below the column index c are not needed for X(c,c) and are zeroed
+// so that they drop out of every later sum; X(c,c) itself goes to diag.
+__device__ __forceinline__ void back_solve(cd (&x)[NB], const double2* L11, int k0, int c, bool okc, double2* diag) {
+#pragma unroll
+    for (int kk = NB - 1; kk >= 0; --kk) {
+        cd sx = x[kk];
+#pragma unroll
+        for (int qq = kk + 1; qq < NB; ++qq) {
+            sx = cmsub(sx, x[qq], L11[kk * NB + qq]);
+            if (((qq - kk) & (SOLVE_BATCH - 1)) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        const double2 rd = L11[kk * NB + kk];
+        sx = sx * mk(rd.x, rd.y);
+        __builtin_amdgcn_sched_barrier(0);
+        x[kk] = (k0 + kk >= c) ? sx : mk(0.0, 0.0);
+        if (okc && k0 + kk == c) diag[c] = make_double2(sx.x, sx.y);
+    }
+}
 // pivot candidate of a row: the high word of |x|^2 (sign 0, 11 exponent and 10 mantissa bits: the modulus to
 // 2^-11) with its 10 lowest bits replaced by 1023 - slot, so that a plain 32-bit maximum picks the largest
 // modulus and, among equals, the first row.  0 = not a candidate / exactly zero; an |x|^2 below 2^-1012 counts
@@ -190,16 +225,7 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk)
                 u[kk] = kk < nbk ? ldg(col + (size_t)rowmap[k0 + kk] * n) : mk(0.0, 0.0);
-#pragma unroll
-            for (int kk = 1; kk < NB; ++kk) {
-                if (kk < nbk) {
-#pragma unroll
-                    for (int c = 0; c < kk; ++c) {
-                        const double2 l = L11[kk * NB + c];
-                        u[kk] = u[kk] - mk(l.x, l.y) * u[c];
-                    }
-                }
-            }
+            t1_solve(u, L11, nbk);
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk)
                 if (kk < nbk) stg(col + (size_t)rowmap[k0 + kk] * n, u[kk]);
@@ -687,16 +713,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
 #pragma unroll
                 for (int kk = 0; kk < NB; ++kk)
                     u[kk] = kk < nbk ? ldg(elem(rowmap[k0 + kk], J)) : mk(0.0, 0.0);
-#pragma unroll
-                for (int kk = 1; kk < NB; ++kk) {
-                    if (kk < nbk) {
-#pragma unroll
-                        for (int c = 0; c < kk; ++c) {
-                            const double2 l = L11[kk * NB + c];
-                            u[kk] = u[kk] - mk(l.x, l.y) * u[c];
-                        }
-                    }
-                }
+                t1_solve(u, L11, nbk);
 #pragma unroll
                 for (int kk = 0; kk < NB; ++kk)
                     if (kk < nbk) stg(elem(rowmap[k0 + kk], J), u[kk]);
@@ -768,32 +785,28 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             const bool okc = c < live;
             cd x[NB];
 #pragma unroll
-            for (int kk = 0; kk < NB; ++kk)
-                x[kk] = (okc && kk < nbk) ? ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]) : mk(0.0, 0.0);
-            // upper-triangular solve in registers; rows below the column index are not
-            // needed for X(c,c) and are zeroed so that they drop out of every later sum
+            for (int kk = 0; kk < NB; ++kk) x[kk] = mk(0.0, 0.0);
+            if (okc) {
+                if (nbk == NB) {  // (uniform: one batch of loads instead of a test per row)
 #pragma unroll
-            for (int kk = NB - 1; kk >= 0; --kk) {
-                if (kk < nbk) {
-                    cd s = x[kk];
+                    for (int kk = 0; kk < NB; ++kk) x[kk] = ldg(&bb[(size_t)__builtin_amdgcn_readfirstlane(rowmap[k0 + kk]) * n + c]);
+                } else {
 #pragma unroll
-                    for (int qq = kk + 1; qq < NB; ++qq) {
-                        if (qq < nbk) {
-                            const double2 uv = L11[kk * NB + qq];
-                            s = s - mk(uv.x, uv.y) * x[qq];
-                        }
-                    }
-                    const double2 rd = L11[kk * NB + kk];
-                    s = s * mk(rd.x, rd.y);
-                    x[kk] = (k0 + kk >= c) ? s : mk(0.0, 0.0);
-                    if (okc && k0 + kk == c) diag[c] = make_double2(s.x, s.y);
+                    for (int kk = 0; kk < NB; ++kk)
+                        if (kk < nbk) x[kk] = ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]);
                 }
             }
+            back_solve(x, L11, k0, c, okc, diag);  // upper-triangular solve in registers
             // the solved block replaces C's block rows: it is the B operand of the update below
             if (okc) {
+                if (nbk == NB) {
 #pragma unroll
-                for (int kk = 0; kk < NB; ++kk)
-                    if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+                    for (int kk = 0; kk < NB; ++kk) stg(&bb[(size_t)__builtin_amdgcn_readfirstlane(rowmap[k0 + kk]) * n + c], x[kk]);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < NB; ++kk)
+                        if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+                }
             }
         }
         __syncthreads();
@@ -1035,32 +1048,28 @@ __device__ __noinline__ void back_substitute(int n_, double2* a_, double2* bb_, 
                 const bool okc = c < live;
                 cd x[NB];
 #pragma unroll
-                for (int kk = 0; kk < NB; ++kk)
-                    x[kk] = (okc && kk < nbk) ? ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]) : mk(0.0, 0.0);
-                // upper-triangular solve in registers; rows below the column index are not
-                // needed for X(c,c) and are zeroed so that they drop out of every later sum
+                for (int kk = 0; kk < NB; ++kk) x[kk] = mk(0.0, 0.0);
+                if (okc) {
+                    if (nbk == NB) {  // (uniform: one batch of loads instead of a test per row)
 #pragma unroll
-                for (int kk = NB - 1; kk >= 0; --kk) {
-                    if (kk < nbk) {
-                        cd sx = x[kk];
+                        for (int kk = 0; kk < NB; ++kk) x[kk] = ldg(&bb[(size_t)__builtin_amdgcn_readfirstlane(rowmap[k0 + kk]) * n + c]);
+                    } else {
 #pragma unroll
-                        for (int qq = kk + 1; qq < NB; ++qq) {
-                            if (qq < nbk) {
-                                const double2 uv = L11[kk * NB + qq];
-                                sx = sx - mk(uv.x, uv.y) * x[qq];
-                            }
-                        }
-                        const double2 rd = L11[kk * NB + kk];
-                        sx = sx * mk(rd.x, rd.y);
-                        x[kk] = (k0 + kk >= c) ? sx : mk(0.0, 0.0);
-                        if (okc && k0 + kk == c) diag[c] = make_double2(sx.x, sx.y);
+                        for (int kk = 0; kk < NB; ++kk)
+                            if (kk < nbk) x[kk] = ldg(&bb[(size_t)rowmap[k0 + kk] * n + c]);
                     }
                 }
+                back_solve(x, L11, k0, c, okc, diag);  // upper-triangular solve in registers
                 // the solved block replaces C's block rows: it is the B operand of the updates below
                 if (okc) {
+                    if (nbk == NB) {
 #pragma unroll
-                    for (int kk = 0; kk < NB; ++kk)
-                        if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+                        for (int kk = 0; kk < NB; ++kk) stg(&bb[(size_t)__builtin_amdgcn_readfirstlane(rowmap[k0 + kk]) * n + c], x[kk]);
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < NB; ++kk)
+                            if (kk < nbk) stg(&bb[(size_t)rowmap[k0 + kk] * n + c], x[kk]);
+                    }
                 }
             }
             __syncthreads();
