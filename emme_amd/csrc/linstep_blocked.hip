@@ -311,6 +311,14 @@ __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* 
     }
 }
 
+#ifdef EMME_LU_STAMPS  // diagnostic build: where the roles of a matrix spend their time (never in the product build)
+__device__ unsigned long long g_lu_stamps[32];
+#define LU_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define LU_ADD(slot, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_lu_stamps[(slot)], (t1) - (t0)); } while (0)
+#else
+#define LU_T(v)
+#define LU_ADD(slot, t0, t1)
+#endif
 // Arguments of a __noinline__ device function arrive in vector registers: the compiler must take them for
 // per-lane values and turns every branch and address that depends on them into exec-mask code (380
 // s_and_saveexec in factor_panel alone).  They are wave-uniform here: say so.
@@ -320,7 +328,12 @@ __device__ __forceinline__ T* uniform(T* p) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
-    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+    // ... and they point to GLOBAL memory (rebuilt as an address-space-1 pointer): otherwise every access
+    // through them is a FLAT one, which counts in lgkmcnt as well as vmcnt -- each wait for an LDS read then
+    // also waits for every load in flight
+    typedef __attribute__((address_space(1))) T GT;
+    GT* g = (GT*)(((unsigned long long)hi << 32) | lo);
+    return (T*)g;
 }
 
 // The panels of a group (first column g0, ng <= GK columns) are factored and published and their row
@@ -342,6 +355,7 @@ __device__ __noinline__ void apply_group(int n_, double2* a_, double2* bb_, int 
     for (int k0 = g0; k0 < g0 + ng; k0 += NB) {
         const int nbk = min(NB, g0 + ng - k0);
         const int nin = g0 + ng - (k0 + nbk);  // pivot rows of the group's later panels
+        LU_T(ta0);
         for (int e = tid; e < NB * NB; e += BT) {
             const int kk = e / NB, c = e % NB;
             L11[e] = (kk < nbk && c < kk) ? a[(size_t)rowmap[k0 + kk] * n + k0 + c] : make_double2(0.0, 0.0);
@@ -351,15 +365,24 @@ __device__ __noinline__ void apply_group(int n_, double2* a_, double2* bb_, int 
             panel[r * LS + c] = c < nbk ? a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] : make_double2(0.0, 0.0);
         }
         __syncthreads();
+        LU_T(ta1);
+        LU_ADD(12, ta0, ta1);
         pivot_rows_update(n, a, bb, rowmap, L11, k0, nbk, Jlo, Jhi, wave, lane);
         __syncthreads();
+        LU_T(ta2);
+        LU_ADD(13, ta1, ta2);
         if (nin > 0) mfma_update<false>(n, a, bb, rowmap, panel, k0 + nbk, nin, k0, nbk, Jlo, Jhi - Jlo, wave, lane);
         __syncthreads();
+        LU_T(ta3);
+        LU_ADD(14, ta2, ta3);
     }
     const int below = n - (g0 + ng);
     if (below > 0) {
+        LU_T(ta4);
         const int rc = max(16, (n * LS / GLS) / 16 * 16);  // rows of multipliers the panel area holds
         mfma_update_grouped<false>(n, a, bb, rowmap, panel, rc, g0 + ng, below, g0, ng, Jlo, Jhi - Jlo, tid, wave, lane);
+        LU_T(ta5);
+        LU_ADD(15, ta4, ta5);
     }
 }
 
@@ -396,14 +419,6 @@ struct SplitCtl {
     int* rowmaps;   // [nbatch][nblk][n]  (nwg > 1 only)
     double2* diag;  // [nbatch][n]
 };
-#ifdef EMME_LU_STAMPS  // diagnostic build: where the roles of a matrix spend their time (never in the product build)
-__device__ unsigned long long g_lu_stamps[32];
-#define LU_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define LU_ADD(slot, t0, t1) do { if (threadIdx.x == 0) atomicAdd(&g_lu_stamps[(slot)], (t1) - (t0)); } while (0)
-#else
-#define LU_T(v)
-#define LU_ADD(slot, t0, t1)
-#endif
 constexpr int ABORT = 1 << 30;
 constexpr int SPIN_LIMIT = 16000000;  // about 4 s
 constexpr int INFO_TIMEOUT = -3;  // EMME_EDEVICE
@@ -1267,6 +1282,10 @@ static void lu_stamps_report(hipStream_t stream) {
     std::fprintf(stderr, "[lu stamps, us per workgroup] role 0 (%llu): panel %.0f publish %.0f trailing %.0f group %.0f wait-helpers %.0f back+wait %.0f | "
                  "helpers (%llu): wait %.0f apply %.0f wait-all %.0f back+wait %.0f\n", h[6], h[0] * r0, h[1] * r0, h[2] * r0, h[3] * r0, h[4] * r0, h[5] * r0,
                  h[20], h[16] * r1, h[17] * r1, h[18] * r1, h[19] * r1);
+    {
+        const double ra = (h[6] + h[20]) ? 1.0 / (100.0 * (h[6] + h[20])) : 0.0;
+        std::fprintf(stderr, "[lu stamps] apply_group (all roles): stage %.0f T1 %.0f in-group MFMA %.0f grouped MFMA %.0f\n", h[12] * ra, h[13] * ra, h[14] * ra, h[15] * ra);
+    }
     std::fprintf(stderr, "[lu stamps] panel: load rows %.0f columns %.0f rank + multipliers to LDS %.0f copy to A + release %.0f\n", h[8] * r0, h[9] * r0,
                  h[10] * r0, h[11] * r0);
     unsigned long long z[32] = {0};
