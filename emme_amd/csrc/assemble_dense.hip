@@ -277,6 +277,28 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     const int loff = tile_index(lane >> 4, lane & 15);  // this lane's element of an MFMA operand load, k-step 0
     const int eoff = (lane >> 5) * 16 + (lane & 15);    // the same for the phase block: node 2 ks + (rho >> 1)
     const double2 omw = A.omega[b];                     // this lane's column omega
+    // The cache geometry, one subtree per lane (lanes 0 .. nsub-1): the slot look-up of an entry is then a few
+    // vector instructions, a ballot and v_readlane's.  (The scalar loop over the subtrees read rd / dd / rp /
+    // base, the buffer pointer and the block counts from the kernel arguments: up to a dozen DEPENDENT scalar
+    // loads per entry below the full tree -- 700 cycles of a vector round's 4 000.)
+    const int g_dfull = A.geom.dfull;
+    const bool g_on = lane < A.geom.nsub;
+    const int gk = g_on ? lane : 0;
+    const int g_rd = A.geom.rd[gk], g_dd = A.geom.dd[gk], g_base = A.geom.base[gk];
+    const unsigned long long g_rp = A.geom.rp[gk];
+    // records of subtree 0 live behind the full tree in the main buffer; the others have buffers of their own
+    const double* g_ptr0 = gk == 0 ? A.recs[0] : A.recs_ext[0][gk - 1];
+    const double* g_ptr1 = gk == 0 ? A.recs[1] : A.recs_ext[1][gk - 1];
+    const unsigned long long g_blk_main = (unsigned long long)tile * (unsigned long long)A.geom.ni_main();
+    // block number of the subtree's first interval for this wave's tile in its buffer
+    const unsigned long long g_blk0 =
+        gk == 0 ? g_blk_main + (unsigned long long)g_base : (unsigned long long)tile * (unsigned long long)((2 << (g_dd - g_rd)) - 1);
+    auto lane_ptr = [&](const double* p, int k) -> const double* {
+        const unsigned long long bits = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, k);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), k);
+        return reinterpret_cast<const double*>(((unsigned long long)hi << 32) | lo);
+    };
     // ---- the wave's 256 integrals: element r of this lane = (pair tile*16 + rho + 4 r, omega col) -----
     unsigned long long mcur[4], mnext[4];  // entries of the current / next level this element needs
     // per-element accumulators live in LDS (touched only by their owner lane, only when the element owns
@@ -335,9 +357,27 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             for (int r = 0; r < 4; ++r) match[r] = ((mcur[r] >> e) & 1ull) != 0ull;
             const unsigned long long need = __ballot(match[0] || match[1] || match[2] || match[3]);
             if (need == 0ull) continue;  // (its owners were deferred meanwhile)
-            int which;
-            const int cslot = A.geom.slot(depth, path, which);
-            const double* ebuf = which >= 0 ? A.recs_ext[ccls][which] : A.recs[ccls];
+            // slot of the interval in the cache and its record block for this tile (CacheGeom::slot, one subtree
+            // per lane: see g_rd above)
+            int cslot;
+            unsigned long long blk;
+            const double* ebuf;
+            if (depth <= g_dfull) {
+                cslot = (1 << depth) - 1 + (int)path;
+                blk = g_blk_main + (unsigned long long)cslot;
+                ebuf = lane_ptr(ccls ? g_ptr1 : g_ptr0, 0);
+            } else {
+                const int sd = (depth - g_rd) & 63;
+                const bool hit = g_on && depth <= g_dd && depth >= g_rd && (path >> sd) == g_rp;
+                const unsigned long long hb = __ballot(hit);
+                const int k = hb ? __builtin_ctzll(hb) : 0;  // (the first subtree that holds it, as the scalar loop)
+                const int rel = (int)((1u << sd) - 1u) + (int)(unsigned)(path & ((1ull << sd) - 1ull));
+                cslot = hb ? __builtin_amdgcn_readlane(g_base + rel, k) : -1;
+                const unsigned long long bl = g_blk0 + (unsigned long long)rel;
+                blk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bl >> 32), k) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bl, k);
+                ebuf = lane_ptr(ccls ? g_ptr1 : g_ptr0, k);
+            }
             if (cslot < 0 || ebuf == nullptr) {
                 // outside the cache: the integrals that need this interval go, whole, to the cooperative kernel
 #pragma unroll
@@ -345,9 +385,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     if (match[r]) defer(r, depth, ccls, path);
                 continue;
             }
-            const double* ablk =
-                which < 0 ? ebuf + ((size_t)tile * A.geom.ni_main() + cslot) * TILE_BLOCK
-                          : ebuf + ((size_t)tile * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * TILE_BLOCK;
+            const double* ablk = ebuf + blk * TILE_BLOCK;
             const double* bblk = A.btab + ((size_t)cslot * A.nchunks + chunk) * BTAB_BLOCK;
             const double2* a2 = reinterpret_cast<const double2*>(ablk);
             const double2* b2 = reinterpret_cast<const double2*>(bblk);
