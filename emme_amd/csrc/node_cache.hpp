@@ -23,6 +23,7 @@ struct NodeRec {  // 48 bytes per (item, interval, node); T = i t~ does not depe
 struct CacheGeom {
     int dfull;
     int nsub;
+    int dmax;  // deepest cached level (max of dfull and the dd's): nothing below it needs a look at the subtrees
     int rd[NODE_CACHE_MAX_SUB], dd[NODE_CACHE_MAX_SUB], base[NODE_CACHE_MAX_SUB];
     unsigned long long rp[NODE_CACHE_MAX_SUB];
     __host__ __device__ int ni_full() const { return (2 << dfull) - 1; }
@@ -34,6 +35,7 @@ struct CacheGeom {
     __device__ int slot(int depth, unsigned long long path, int& which) const {
         which = -1;
         if (depth <= dfull) return (1 << depth) - 1 + (int)path;
+        if (depth > dmax) return -1;
         for (int k = 0; k < nsub; ++k) {
             if (depth <= dd[k] && depth >= rd[k]) {
                 const int sd = depth - rd[k];
@@ -98,6 +100,8 @@ inline CacheGeom make_geom(const NodeCacheGeom& g) {
     CacheGeom c;
     c.dfull = g.dfull;
     c.nsub = g.nsub;
+    c.dmax = g.dfull;
+    for (int k = 0; k < g.nsub && k < NODE_CACHE_MAX_SUB; ++k) c.dmax = g.dd[k] > c.dmax ? g.dd[k] : c.dmax;
     int base = c.ni_full();
     for (int k = 0; k < NODE_CACHE_MAX_SUB; ++k) {
         c.rd[k] = k < g.nsub ? g.rd[k] : 0;
