@@ -58,15 +58,25 @@ struct AsmArgs {
 // the spot only for uncached intervals.  Used for integrals the cached kernel deferred and for
 // omegas whose integrals are so long that their serial latency matters more than throughput:
 // here all 15 (31) nodes of an interval advance in parallel.
+// (the tables of the omega's contour class: a caller whose omega is fixed for many intervals -- the cooperative
+// kernel -- reads the three pointers once per integral instead of once per interval, a scalar load and a wait each)
+struct ClassTables {
+    const NodeRec* recs;
+    const double2* ttab;
+    const double2* wtab;
+};
+__device__ __forceinline__ ClassTables class_tables(const AsmArgs& A, int cls) {
+    return ClassTables{A.recs[cls], A.ttab[cls], A.wtab[cls]};
+}
 template <int GW>
-__device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned long long path,
+__device__ __forceinline__ cd node_value(const AsmArgs& A, const ClassTables& ct, int depth, unsigned long long path,
                                          long cache_item, int lane_in_group, double x,
                                          const PairConst& pc, const OmegaConst& oc, int m,
                                          const TransConsts& tc) {
     const int cls = oc.omi > 0.0 ? 0 : 1;
     int which;
-    const int cslot = A.recs[cls] ? A.geom.slot(depth, path, which) : -1;
-    const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? A.recs[cls] : A.recs_ext[cls][which]);
+    const int cslot = ct.recs ? A.geom.slot(depth, path, which) : -1;
+    const NodeRec* buf = cslot < 0 ? nullptr : (which < 0 ? ct.recs : A.recs_ext[cls][which]);
     NodeData d;
     if (buf && A.tiled) {
         // tiled layout (electrostatic GK15, folded): block of the pair's tile, node slot of this lane
@@ -79,7 +89,7 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
         const int sn = slotnode_of_lane(lane_in_group);
         const double4 ra = *reinterpret_cast<const double4*>(reinterpret_cast<const double2*>(blk) + tile_index(2 * sn, p));
         const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);  // (Q1, Q0) of the node: one 32-byte piece
-        const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
+        const double2 tt = ct.ttab[(long)cslot * GW + lane_in_group];
         const cd arg = mk(tt.x, tt.y) * oc.omega;
         // (no safe_exp clamp on tiled records, like the dense fill that shares them: node_cache.hpp;
         // exp(T omega) below -745 underflows to an exact 0 by itself)
@@ -89,18 +99,18 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, int depth, unsigned l
         return mk(ea * ca, ea * sa) * (oc.omega * q1 + q0);
     }
     if (buf) {
-        const bool shared = A.wtab[cls] != nullptr;
+        const bool shared = ct.wtab != nullptr;
         const long ci = shared ? cache_item / A.P.nm : cache_item;
         const NodeRec rec =
             which < 0 ? buf[(ci * A.geom.ni_main() + cslot) * GW + lane_in_group]
                       : buf[(ci * A.geom.ni_sub(which + 1) + (cslot - A.geom.base[which + 1])) * GW +
                             lane_in_group];
-        const double2 tt = A.ttab[cls][(long)cslot * GW + lane_in_group];
+        const double2 tt = ct.ttab[(long)cslot * GW + lane_in_group];
         d.T = mk(tt.x, tt.y);
         d.Q1 = mk(rec.Q1.x, rec.Q1.y);
         d.Q0 = mk(rec.Q0.x, rec.Q0.y);
         if (shared && m > 0) {
-            const double2 ww = A.wtab[cls][(long)cslot * GW + lane_in_group];
+            const double2 ww = ct.wtab[(long)cslot * GW + lane_in_group];
             cd nv = pc.c_nv * mk(ww.x, ww.y);
             if (m == 2) nv = nv * nv;
             d.Q1 = d.Q1 * nv;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
 
         const long cache_item = LIST ? (long)(A.worklist[item] & 0xffffffffull) : (long)item;
         const cd f = (LIST || A.recs[oc.omi > 0.0 ? 0 : 1] != nullptr)
-                         ? node_value<GW>(A, depth, path, cache_item, lane_in_group, x, pc, oc, m, TC)
+                         ? node_value<GW>(A, class_tables(A, oc.omi > 0.0 ? 0 : 1), depth, path, cache_item, lane_in_group, x, pc, oc, m, TC)
                          : integrand(x, P, pc, oc, m);
         const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
         const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
@@ -393,6 +403,7 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
         const int i = ij.x, j = ij.y;
         const double dg = gtab[i] - gtab[j];
         const PairConst pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], dg);
+        const ClassTables ct = class_tables(A, oc.omi > 0.0 ? 0 : 1);
 
         // one interval: GK estimate, error, accept/split (include/functions.h:203-208, 231-247)
         double abs_tol = 0.0;
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
             mid = (r + l) / 2;
             const double scale = (r - l) / 2;
             const double x = __dadd_rn(__dmul_rn(scale, gk.x), mid);
-            const cd f = node_value<GW>(A, depth, path, (long)it, lane_in_group, x, pc, oc, m, TC);
+            const cd f = node_value<GW>(A, ct, depth, path, (long)it, lane_in_group, x, pc, oc, m, TC);
             const double Kx = group_sum<GW>(gk.wk * f.x), Ky = group_sum<GW>(gk.wk * f.y);
             const double Gx = group_sum<GW>(gk.wg * f.x), Gy = group_sum<GW>(gk.wg * f.y);
             const double dKx = Kx - Gx, dKy = Ky - Gy;
