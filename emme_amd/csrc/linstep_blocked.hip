@@ -341,7 +341,7 @@ __device__ __forceinline__ T* uniform(T* p) {
 // (T1) and the group's later pivot rows, then ONE pass over the rows below the group with all of the
 // group's multipliers.  Not inlined: the panel loop of the kernel lives on a 128-register budget of its
 // own (inlined, this costs it 230 more spilled registers).  The LDS areas are the kernel's (dynamic LDS:
-// rowmap | physrow | pivof | L11 | prow | panel).
+// rowmap | physrow | pivof | L11 | NB spare entries | panel).
 __device__ __noinline__ void apply_group(int n_, double2* a_, double2* bb_, int g0_, int ng_, int Jlo_, int Jhi_) {
     const int n = uniform(n_), g0 = uniform(g0_), ng = uniform(ng_), Jlo = uniform(Jlo_), Jhi = uniform(Jhi_);
     double2* a = uniform(a_);
@@ -445,8 +445,9 @@ template <bool SPLIT, bool CHUNK = false>
 __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, double2* A, double2* B,
                                                             const int* active, double2* tr_out,
                                                             int* info_out, SplitCtl ctl) {
-    // dynamic LDS: rowmap[n] | physrow[n] | pivof[n] (ints) | L11[NB][NB] | prow[NB] |
-    //              panel[n][NB] (L21 in the forward phase, U column block in the back phase)
+    // dynamic LDS: rowmap[n] | physrow[n] | pivof[n] (ints) | L11[NB][NB] | NB spare entries |
+    //              panel[n][NB] (L21 in the forward phase, U column block in the back phase; during a
+    //              panel's column loop its first 8 KB hold the waves' candidate pivot rows)
     extern __shared__ double2 lds2[];
     __shared__ BlkShared sh;
 
@@ -599,10 +600,9 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         for (int kk = 0; kk < NB; ++kk) {
             if (kk < nbk) {  // uniform
                 // pivot search: max modulus among rows not yet used in this block.  Candidates
-                // are 64-bit keys: the modulus' bit pattern (non-negative doubles order like
-                // integers) with its 10 lowest bits replaced by 1023 - slot, so that a plain
-                // integer maximum picks the largest modulus (to 2^-42) and, among equals, the
-                // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
+                // are 32-bit keys (pivot_key: the high word of |x|^2 with its 10 lowest bits
+                // replaced by 1023 - slot), so that a plain integer maximum picks the largest
+                // modulus (to 2^-11) and, among equals, the first row.  Wave maximum by DPP.
                 unsigned int key = 0;
                 if (tid < nrem && mypiv < 0) key = pivot_key(norm2(pr[kk]), tid);
                 const unsigned int wkey = wave_max32(key);
@@ -914,10 +914,9 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
     for (int kk = 0; kk < NB; ++kk) {
         if (kk < nbk) {  // uniform
             // pivot search: max modulus among rows not yet used in this block.  Candidates
-            // are 64-bit keys: the modulus' bit pattern (non-negative doubles order like
-            // integers) with its 10 lowest bits replaced by 1023 - slot, so that a plain
-            // integer maximum picks the largest modulus (to 2^-42) and, among equals, the
-            // first row.  Wave maximum by DPP, one LDS word per wave, one barrier.
+            // are 32-bit keys (pivot_key: the high word of |x|^2 with its 10 lowest bits
+            // replaced by 1023 - slot), so that a plain integer maximum picks the largest
+            // modulus (to 2^-11) and, among equals, the first row.  Wave maximum by DPP.
             unsigned int key = 0;
             if (tid < nrem && mypiv < 0) key = pivot_key(norm2(pr[kk]), tid);
             const unsigned int wkey = wave_max32(key);
