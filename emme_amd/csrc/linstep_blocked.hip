@@ -469,8 +469,6 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     int* rowmap = reinterpret_cast<int*>(lds2);  // logical position -> physical row
-    int* physrow = rowmap + n;                   // remaining-row slot t -> physical row
-    int* pivof = physrow + n;                    // slot t -> pivot index in this block or -1
     double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
     double2* panel = L11 + NB * NB + NB;
     double2* cand = panel;  // [2][BW][NB] candidate pivot rows of the panel loop (the area is free during it)
@@ -646,13 +644,17 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
         // (pivots per wave, for the ranks below)
         const unsigned long long pbal = __ballot(tid < nrem && mypiv >= 0);
         if ((tid & 63) == 0) sh.s_idx[tid >> 6] = __popcll(pbal);
-        if (tid < nrem) {
-            pivof[tid] = mypiv;
-            if (mypiv >= 0) {
-                // this row is pivot k0+mypiv: its panel entries from column mypiv on are U
+        // A pivot row goes back to A in place, whole: U from its pivot on, its multipliers left of it (the
+        // helpers read them there).  ONE masked region of 16 stores -- with a test per column (c >= mypiv)
+        // every store sat behind a wait for the one before it, 2.8 us per panel.
+        if (tid < nrem && mypiv >= 0) {
+            if (nbk == NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
+            } else {
 #pragma unroll
                 for (int c = 0; c < NB; ++c)
-                    if (c >= mypiv && c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
+                    if (c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
             }
         }
         __syncthreads();
@@ -688,11 +690,7 @@ __global__ __launch_bounds__(BT) void k_trace_solve_blocked(int n, int nbatch, d
             // of the pivots; copied here from LDS) and the row order from a snapshot
             const int kblk = k0 / NB;
             if (tid < nrem) snap[(size_t)kblk * n + k0 + tid] = rowmap[k0 + tid];
-            for (int e = tid; e < NB * NB; e += BT) {
-                const int kk = e / NB, c = e % NB;
-                if (kk < nbk && c < kk) a[(size_t)rowmap[k0 + kk] * n + k0 + c] = L11[e];
-            }
-            if (!CHUNK) {
+            if (!CHUNK) {  // the other rows' multipliers: from LDS, 16 lanes per row
                 for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
                     const int r = e / NB, c = e % NB;
                     if (c < nbk) a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] = panel[r * LS + c];
@@ -883,7 +881,6 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
     __shared__ BlkShared shp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* rowmap = reinterpret_cast<int*>(lds2);
-    int* pivof = rowmap + 2 * n;
     double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
     double2* panel = L11 + NB * NB + NB;
     double2* cand = panel;  // [2][BW][NB] candidate pivot rows: the panel area is free until the multipliers go there
@@ -960,13 +957,15 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
     // (pivots per wave, for the ranks below)
     const unsigned long long pbal = __ballot(tid < nrem && mypiv >= 0);
     if (lane == 0) shp.s_idx[wave] = __popcll(pbal);
-    if (tid < nrem) {
-        pivof[tid] = mypiv;
-        if (mypiv >= 0) {
-            // this row is pivot k0+mypiv: its panel entries from column mypiv on are U
+    // a pivot row goes back to A in place, whole (see the kernel): U from the pivot on, its multipliers left of it
+    if (tid < nrem && mypiv >= 0) {
+        if (nbk == NB) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
+        } else {
 #pragma unroll
             for (int c = 0; c < NB; ++c)
-                if (c >= mypiv && c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
+                if (c < nbk) stg(&a[(size_t)myrow * n + k0 + c], pr[c]);
         }
     }
     __syncthreads();
@@ -998,11 +997,7 @@ __device__ __noinline__ int factor_panel(int n_, double2* a_, int k0_, int* snap
         // of the pivots; copied here from LDS) and the row order from a snapshot
         const int kblk = k0 / NB;
         if (tid < nrem) snap[(size_t)kblk * n + k0 + tid] = rowmap[k0 + tid];
-        for (int e = tid; e < NB * NB; e += BT) {
-            const int kk = e / NB, c = e % NB;
-            if (kk < nbk && c < kk) a[(size_t)rowmap[k0 + kk] * n + k0 + c] = L11[e];
-        }
-        for (int e = tid; e < (nrem - nbk) * NB; e += BT) {
+        for (int e = tid; e < (nrem - nbk) * NB; e += BT) {  // the other rows' multipliers: from LDS, 16 lanes per row
             const int r = e / NB, c = e % NB;
             if (c < nbk) a[(size_t)rowmap[k0 + nbk + r] * n + k0 + c] = panel[r * LS + c];
         }
