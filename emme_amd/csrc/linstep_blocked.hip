@@ -180,12 +180,15 @@ __device__ __forceinline__ void mfma_update(int n, double2* a, double2* bb, cons
             const int rc = rr < nrows ? rr : nrows - 1;
             px[r] = colbase + (size_t)rowmap[crow0 + rc] * n;
         }
+        // (all four loads first, into registers of their own: unpacked one by one into the accumulator
+        // vectors they shared temporaries, and each load waited for the one before it)
         d4 cre, cim;
+        double2 cx[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double2 x = *px[r];
-            cre[r] = x.x, cim[r] = x.y;
-        }
+        for (int r = 0; r < 4; ++r) cx[r] = *px[r];
+        asm volatile("" : "+v"(cx[0].x), "+v"(cx[0].y), "+v"(cx[1].x), "+v"(cx[1].y), "+v"(cx[2].x), "+v"(cx[2].y), "+v"(cx[3].x), "+v"(cx[3].y));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cre[r] = cx[r].x, cim[r] = cx[r].y;
         const int ri = rt * 16 + i16;
         const int ric = ri < nrows ? ri : nrows - 1;
         double nare[4], aim[4];
@@ -273,11 +276,12 @@ __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* 
                 px[r] = colbase + (size_t)rowmap[crow0 + r0 + rcl] * n;
             }
             d4 cre, cim;
+            double2 cx[4];  // (all four loads first: see mfma_update)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double2 x = *px[r];
-                cre[r] = x.x, cim[r] = x.y;
-            }
+            for (int r = 0; r < 4; ++r) cx[r] = *px[r];
+            asm volatile("" : "+v"(cx[0].x), "+v"(cx[0].y), "+v"(cx[1].x), "+v"(cx[1].y), "+v"(cx[2].x), "+v"(cx[2].y), "+v"(cx[3].x), "+v"(cx[3].y));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cre[r] = cx[r].x, cim[r] = cx[r].y;
             const int ri = rt * 16 + i16;
             const int ric = ri < nr ? ri : nr - 1;
             const int nq = (nk + NB - 1) / NB;
