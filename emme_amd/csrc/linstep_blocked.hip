@@ -259,6 +259,88 @@ __device__ __forceinline__ void mfma_update_grouped(int n, double2* a, double2* 
         }
         __syncthreads();
         const int nrt = (nr + 15) >> 4;
+        if (!LOWER) {
+        // forward sweep: TWO row tiles per wave and trip: they share the loads of the B operand (the U rows, 4 loads per 16
+        // k-steps), which is what the pass waits for -- per element the same MFMA sequence as one tile at a time
+        const int nrp = (nrt + 1) >> 1;
+        for (int tile = wave; tile < nrp * nct; tile += BW) {
+            const int ct = tile / nrp, rp = tile - ct * nrp;
+            const int rt0 = 2 * rp, rt1 = 2 * rp + 1;
+            const bool on0 = !(LOWER && ct > rt0 + (r0 >> 4));                 // wave-uniform
+            const bool on1 = rt1 < nrt && !(LOWER && ct > rt1 + (r0 >> 4));    // wave-uniform
+            if (!on0 && !on1) continue;
+            const int J = col0 + ct * 16 + i16;
+            const bool okc = J < col0 + ncols;
+            const int Jc = okc ? J : col0 + ncols - 1;
+            double2* colbase = Jc < n ? a + Jc : bb + (Jc - n);
+            int poff[2][4];  // row offsets of the C entries (elements: n^2 < 2^31)
+            bool okr[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = (2 * rp + h) * 16 + kq + 4 * r;
+                    okr[h][r] = (h ? on1 : on0) && okc && rr < nr;
+                    const int rcl = rr < nr ? rr : nr - 1;
+                    poff[h][r] = rowmap[crow0 + r0 + rcl] * n;
+                }
+            }
+            d4 cre[2], cim[2];
+            double2 cx[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cx[h][r] = colbase[poff[h][r]];
+            asm volatile("" : "+v"(cx[0][0].x), "+v"(cx[0][0].y), "+v"(cx[0][1].x), "+v"(cx[0][1].y), "+v"(cx[0][2].x), "+v"(cx[0][2].y), "+v"(cx[0][3].x), "+v"(cx[0][3].y));
+            asm volatile("" : "+v"(cx[1][0].x), "+v"(cx[1][0].y), "+v"(cx[1][1].x), "+v"(cx[1][1].y), "+v"(cx[1][2].x), "+v"(cx[1][2].y), "+v"(cx[1][3].x), "+v"(cx[1][3].y));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cre[h][r] = cx[h][r].x, cim[h][r] = cx[h][r].y;
+            const int ri0 = rt0 * 16 + i16, ri1 = rt1 * 16 + i16;
+            const int ric0 = ri0 < nr ? ri0 : nr - 1, ric1 = ri1 < nr ? ri1 : nr - 1;
+            const int nq = (nk + NB - 1) / NB;
+            for (int qq = 0; qq < nq; ++qq) {
+                const int q = LOWER ? nq - 1 - qq : qq;
+                double nare0[4], aim0[4], nare1[4], aim1[4], bre[4], bim[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = q * NB + 4 * ks + kq;
+                    const int kc = k < nk ? k : nk - 1;
+                    const double2 u = colbase[(size_t)rowmap[k0 + kc] * n];
+                    const bool okb = okc && k < nk;
+                    bre[ks] = okb ? u.x : 0.0, bim[ks] = okb ? u.y : 0.0;
+                    const double2 l0 = buf[ric0 * GLS + kc], l1 = buf[ric1 * GLS + kc];
+                    const bool oka0 = ri0 < nr && k < nk, oka1 = ri1 < nr && k < nk;
+                    nare0[ks] = oka0 ? -l0.x : 0.0, aim0[ks] = oka0 ? l0.y : 0.0;
+                    nare1[ks] = oka1 ? -l1.x : 0.0, aim1[ks] = oka1 ? l1.y : 0.0;
+                }
+                if (on0) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        cre[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(nare0[ks], bre[ks], cre[0], 0, 0, 0);
+                        cim[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(nare0[ks], bim[ks], cim[0], 0, 0, 0);
+                        cre[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim0[ks], bim[ks], cre[0], 0, 0, 0);
+                        cim[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim0[ks], bre[ks], cim[0], 0, 0, 0);
+                    }
+                }
+                if (on1) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        cre[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nare1[ks], bre[ks], cre[1], 0, 0, 0);
+                        cim[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(nare1[ks], bim[ks], cim[1], 0, 0, 0);
+                        cre[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim1[ks], bim[ks], cre[1], 0, 0, 0);
+                        cim[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim1[ks], bre[ks], cim[1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (okr[h][r]) colbase[poff[h][r]] = make_double2(cre[h][r], cim[h][r]);
+        }
+        } else
         for (int tile = wave; tile < nrt * nct; tile += BW) {
             const int ct = tile / nrt, rt = tile - ct * nrt;
             if (LOWER && ct > rt + (r0 >> 4)) continue;  // wave-uniform
