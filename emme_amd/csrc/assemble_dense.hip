@@ -627,6 +627,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         atomicAdd(&A.stats[7], cyc_dec);
         atomicAdd(&A.stats[8], __builtin_amdgcn_s_memtime() - t_task);
         atomicMax(&A.stats[9], __builtin_amdgcn_s_memtime() - t_task);
+        if (tile < 8192) atomicAdd(&A.stats[16 + tile], __builtin_amdgcn_s_memtime() - t_task);
     }
 #endif
     if (lane == 0) {

@@ -309,8 +309,8 @@ int ensure_batch(emme_ctx* c, int nb) {
         c->p_cap = nb, c->p_lists_cap = 4 * nb;
     }
     if (!c->d_rounds) {
-        HIP_TRY(malloc_retry((void**)&c->d_rounds, 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_rounds, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(malloc_retry((void**)&c->d_rounds, (16 + 8192) * sizeof(unsigned long long)));  // (+ per-tile ticks of the diagnostic build)
+        HIP_TRY(hipMemset(c->d_rounds, 0, (16 + 8192) * sizeof(unsigned long long)));
     }
     c->cap = nb;
     return EMME_OK;
@@ -788,6 +788,17 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                     fprintf(stderr, "[emme] dense launch: %d omegas in %d chunks, %.0f tasks, %.3f ms; task ticks: mean %.0f, longest %.0f, "
                             "sum / 2048 wave slots %.0f; rounds dense %llu sparse %llu\n", n_lane, nchunks, tasks, ms,
                             tasks > 0 ? tot / tasks : 0.0, (double)r1[9], tot / 2048.0, r1[0] - r0[0], r1[1] - r0[1]);
+                    {   // how the tiles' times are spread (all chunks of the launch added up per tile)
+                        const size_t nt = std::min<size_t>(((size_t)c->npairs + 15) / 16, 8192);
+                        std::vector<unsigned long long> tt(nt);
+                        HIP_TRY(hipMemcpy(tt.data(), c->d_rounds + 16, nt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemset(c->d_rounds + 16, 0, nt * sizeof(unsigned long long)));
+                        // first, middle and last tiles in index order, then percentiles
+                        fprintf(stderr, "[emme]   tile ticks by index: %llu %llu %llu %llu %llu | ", tt[0], tt[nt / 4], tt[nt / 2], tt[3 * nt / 4], tt[nt - 1]);
+                        std::sort(tt.begin(), tt.end());
+                        fprintf(stderr, "sorted: min %llu p25 %llu p50 %llu p75 %llu p90 %llu p97 %llu max %llu\n", tt[0], tt[nt / 4], tt[nt / 2],
+                                tt[3 * nt / 4], tt[nt * 9 / 10], tt[nt * 97 / 100], tt[nt - 1]);
+                    }
                     (void)hipEventDestroy(e0);
                     (void)hipEventDestroy(e1);
                 }
