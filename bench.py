@@ -408,25 +408,17 @@ def main():
 
     # ---- side measurement (rank 0, cfg 3): the same search without the node cache (a one-shot caller)
     if rank == 0 and cfg == 3 and not args.no_cold and world == 1:
-        old = os.environ.get("EMME_NODE_CACHE_GB")
-        os.environ["EMME_NODE_CACHE_GB"] = "0"
-        try:
-            with emme_amd.Context(emme_amd.params_from_dict(d), device=local_rank) as c0:
-                c0.set_stream(stream.cuda_stream)
-                c0.solve_roots(guesses)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                rn, inn, fn = c0.solve_roots(guesses)
-                torch.cuda.synchronize()
-                tn = time.perf_counter() - t1
-                cold["no_cache_omega_points_per_s"] = float(inn[fn == 0].sum()) / tn
-                cold["no_cache_ms_per_step"] = tn * 1e3
-                cold["no_cache_fill_kernel"] = c0.fill_kernel()
-        finally:
-            if old is None:
-                os.environ.pop("EMME_NODE_CACHE_GB", None)
-            else:
-                os.environ["EMME_NODE_CACHE_GB"] = old
+        with emme_amd.Context(emme_amd.params_from_dict(d), device=local_rank, node_cache_gb=0.0) as c0:
+            c0.set_stream(stream.cuda_stream)
+            c0.solve_roots(guesses)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rn, inn, fn = c0.solve_roots(guesses)
+            torch.cuda.synchronize()
+            tn = time.perf_counter() - t1
+            cold["no_cache_omega_points_per_s"] = float(inn[fn == 0].sum()) / tn
+            cold["no_cache_ms_per_step"] = tn * 1e3
+            cold["no_cache_fill_kernel"] = c0.fill_kernel()
 
     if rank == 0:
         out = {

@@ -69,7 +69,47 @@ class Profile(C.Structure):
         ("cache_alloc_ms", C.c_double),
         ("dense_rounds", C.c_longlong), ("sparse_rounds", C.c_longlong),
         ("sparse_columns", C.c_longlong), ("tile_tasks", C.c_longlong),
+        ("nullspace_ms", C.c_double), ("nullspace_launches", C.c_long),
     ]
+
+
+FILL_AUTO, FILL_UNION, FILL_LANES = 0, 1, 2
+
+
+class Options(C.Structure):
+    """emme_options_t: per-context options (cache budget, fill routing, LU split ...)."""
+
+    _fields_ = [
+        ("size", C.c_int),
+        ("node_cache_gb", C.c_double), ("cache_min_batch", C.c_int), ("cache_min_depth", C.c_int),
+        ("fill", C.c_int), ("phase_table", C.c_int), ("em_shared", C.c_int), ("wl_min", C.c_int),
+        ("union_sel", C.c_int), ("union_ipg_few", C.c_int), ("union_few_chunks", C.c_int),
+        ("coop_wide_min", C.c_int), ("defer_one_group", C.c_int),
+        ("dense_min_cols", C.c_int), ("dense_min_tasks", C.c_int), ("dense_cost_ratio", C.c_double),
+        ("skip_lost", C.c_int),
+        ("lu_split", C.c_int), ("lu_group_min_n", C.c_int), ("lu_spin_limit", C.c_int),
+        ("lu_unblocked", C.c_int),
+    ]
+
+
+# options every new Context starts from (the tests build their node cache for a handful of omegas)
+_DEFAULT_OPTIONS: dict = {}
+
+
+def set_default_options(**kw) -> None:
+    """Python-side defaults merged into every Context created afterwards (explicit arguments win)."""
+    _DEFAULT_OPTIONS.clear()
+    _DEFAULT_OPTIONS.update(kw)
+
+
+def default_options(**kw) -> Options:
+    o = Options()
+    load().emme_options_default(C.byref(o))
+    for k, v in {**_DEFAULT_OPTIONS, **kw}.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown option {k!r}")
+        setattr(o, k, v)
+    return o
 
 
 def load():
@@ -92,6 +132,12 @@ def load():
     lib.emme_weight.restype = C.c_double
     lib.emme_bessel_batch.argtypes = [P, C.c_int, P]
     lib.emme_ctx_create.argtypes = [PP, C.c_int, C.POINTER(P)]
+    lib.emme_options_default.argtypes = [C.POINTER(Options)]
+    lib.emme_options_default.restype = None
+    lib.emme_ctx_create_ex.argtypes = [PP, C.c_int, C.POINTER(Options), C.POINTER(P)]
+    lib.emme_ctx_set_options.argtypes = [P, C.POINTER(Options)]
+    lib.emme_ctx_get_options.argtypes = [P, C.POINTER(Options)]
+    lib.emme_null_vectors_batch.argtypes = [P, C.c_int, C.c_int, P, P, P]
     lib.emme_ctx_destroy.argtypes = [P]
     lib.emme_ctx_destroy.restype = None
     lib.emme_release_pooled_memory.argtypes = []
@@ -284,13 +330,28 @@ def _c128(a, shape=None):
 class Context:
     """One (device, parameter set): owns device tables and batch scratch."""
 
-    def __init__(self, params: Params, device: int = -1):
+    def __init__(self, params: Params, device: int = -1, **options):
+        """options: fields of emme_options_t (node_cache_gb, cache_min_batch, fill, lu_split, ...)."""
         self.lib = load()
         self.params = params
         h = C.c_void_p()
-        _check(self.lib.emme_ctx_create(C.byref(params), device, C.byref(h)))
+        o = default_options(**options)
+        _check(self.lib.emme_ctx_create_ex(C.byref(params), device, C.byref(o), C.byref(h)))
         self.h = h
         self.dim = self.lib.emme_ctx_dim(h)
+
+    def options(self) -> Options:
+        o = Options()
+        _check(self.lib.emme_ctx_get_options(self.h, C.byref(o)))
+        return o
+
+    def set_options(self, **kw) -> None:
+        o = self.options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k!r}")
+            setattr(o, k, v)
+        _check(self.lib.emme_ctx_set_options(self.h, C.byref(o)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -325,11 +386,12 @@ class Context:
         mode = self.lib.emme_ctx_fill_mode(self.h)
         pts = self.params.integration_start_points
         em = self.params.beta_e != 0.0
-        folded = "false" if os.environ.get("EMME_PHASE_TABLE") == "0" else "true"
+        o = self.options()
+        folded = "true" if o.phase_table else "false"
         if mode == 4:
             return "k_assemble_dense"
         if mode == 3:
-            return "k_assemble_union<15, %d>" % int(os.environ.get("EMME_UNION_SEL", "2"))
+            return "k_assemble_union<15, %d>" % o.union_sel
         if mode == 2:
             return f"k_assemble_cached_em<{pts}, {folded}>" if em else f"k_assemble_cached<{pts}, {folded}>"
         if mode == 1:
@@ -374,6 +436,12 @@ class Context:
         _check(self.lib.emme_assemble_batch(self.h, w.ctypes.data, nb,
                                             C.c_void_p(out_device_ptr), iv.ctypes.data))
         return iv
+
+    def assemble_rc(self, omegas) -> int:
+        """emme_assemble_batch's return code alone (0, or EMME_ENUMERIC when a matrix holds a non-finite integral)."""
+        w = _c128(np.atleast_1d(omegas))
+        M = np.zeros((w.shape[0], self.dim, self.dim), dtype=np.complex128)
+        return self.lib.emme_assemble_batch(self.h, w.ctypes.data, w.shape[0], M.ctypes.data, None)
 
     def trace_solve(self, A, B):
         A = _c128(A).copy()
@@ -430,6 +498,23 @@ class Context:
                                          roots.ctypes.data, iters.ctypes.data, info.ctypes.data,
                                          its.ctypes.data if want_iterates else None))
         return (roots, iters, info, its) if want_iterates else (roots, iters, info)
+
+    def null_vectors(self, M=None, nbatch=None):
+        """nullSpace (include/solver.h:58-112) on the device, batched: right singular vector of the smallest
+        singular value of every matrix.  M = None: the matrices M(omega_final) of the last solve_roots call.
+        Returns (vectors [nbatch, n], info [nbatch])."""
+        if M is None:
+            n, nb, ptr = self.dim, nbatch, None
+        else:
+            M = _c128(M)
+            if M.ndim == 2:
+                M = M[None]
+            M = np.ascontiguousarray(M)
+            nb, n, ptr = M.shape[0], M.shape[1], M.ctypes.data
+        v = np.zeros((nb, n), dtype=np.complex128)
+        info = np.zeros(nb, dtype=np.int32)
+        _check(self.lib.emme_null_vectors_batch(self.h, n, nb, ptr, v.ctypes.data, info.ctypes.data))
+        return v, info
 
     def final_matrix(self, b=0):
         M = np.zeros((self.dim, self.dim), dtype=np.complex128)

@@ -51,6 +51,7 @@ struct AsmArgs {
     int folded;  // cached records are in the folded form (exp(A0) inside the amplitudes)
     int tiled;   // the cache is in the tiled layout of the dense fill (node_cache.hpp): `recs` point to doubles
     unsigned int count_lo, count_hi;  // k_assemble_coop: run only if count_lo <= list length < count_hi
+    int skip_lost;  // LIST mode: integrals of a matrix whose status flag is already set are skipped
 };
 
 // Value of the integrand at one quadrature node when a node-record cache may hold the
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     __shared__ int s_cnt[NG];
     __shared__ double s_part[NG][2];
     __shared__ int s_bad;
+    __shared__ int s_lost[2];
 
     const DevParams& P = A.P;
 #ifdef EMME_COOP_SREG_CONSTS
@@ -390,10 +392,21 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     const int nitems = (int)*A.worklist_count;
     if ((unsigned)nitems < A.count_lo || (unsigned)nitems >= A.count_hi) return;  // the other variant's list
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int trip = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++trip) {
         const unsigned long long e = A.worklist[item];
         const int it = (int)(e & 0xffffffffull);
         const int b = (int)(e >> 32);
+        if (A.skip_lost) {
+            // The matrix already holds a non-finite integral (this kernel's own `isbad`, or the cached fill's):
+            // its chain retires at the next Newton step whatever else goes into it (the reference's zsysv fails
+            // on such a matrix, include/solver.h:142-153) -- the rest of its integrals, thousands of intervals
+            // each from scratch, are not worth a cycle.  One thread reads the flag for the workgroup (the slot
+            // alternates: the next write to it is two barriers away).
+            if (threadIdx.x == 0) s_lost[trip & 1] = A.status[b];
+            __syncthreads();
+            if (s_lost[trip & 1] != 0) continue;
+        }
         OmegaConst oc;
         oc.omega = mk(A.omega[b].x, A.omega[b].y);
         oc.omi = -copysign(1.0, oc.omega.x);
@@ -549,6 +562,7 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const No
     A.domega = (const double2*)L.domega;
     A.intervals = L.intervals;
     A.status = L.status;
+    A.skip_lost = L.skip_lost;
     A.worklist = nullptr;
     A.worklist_count = nullptr;
     A.folded = 0;
@@ -602,6 +616,7 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     A.domega = (const double2*)L.domega;
     A.intervals = L.intervals;
     A.status = L.status;
+    A.skip_lost = L.skip_lost;
     A.worklist = worklist;
     A.worklist_count = count;
     A.folded = folded ? 1 : 0;
@@ -616,15 +631,14 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     dim3 grid(2048), block(256);
-    static const bool one_group = std::getenv("EMME_DEFER_ONE_GROUP") != nullptr;
+    const bool one_group = L.defer_one_group != 0;
     if (!one_group) {
         // a workgroup per integral (see k_assemble_coop): 256 threads for a short list (few, long
         // integrals: as many lane groups per integral as its frontier can feed), one wave for a
         // long one (thousands of integrals, mostly deep and narrow: more of them in flight and
         // wave-level barriers).  The list length is on the device: both variants are launched
         // and the one whose range it is not in returns at once.
-        const char* wide_s = std::getenv("EMME_COOP_WIDE_MIN");
-        const unsigned int wide_min = wide_s ? (unsigned int)std::atol(wide_s) : 4096u;
+        const unsigned int wide_min = (unsigned int)L.coop_wide_min;  // (-1 = never: 0xffffffff)
         const size_t tab_bytes = ((size_t)3 * L.P.N + (3 * L.P.N & 1)) * sizeof(double);
         A.count_lo = 0, A.count_hi = wide_min;
         if (L.gk_points == 15)

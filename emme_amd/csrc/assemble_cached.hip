@@ -184,6 +184,7 @@ struct AsmCachedArgs {
     const double2* domega;
     unsigned long long* intervals;
     int* status;
+    int skip_lost;  // omegas whose matrix is already flagged (status) are left alone
 };
 
 #ifndef EMME_CACHED_MIN_WAVES
@@ -222,9 +223,10 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
     while (n_eff < n_in_chunk) n_eff <<= 1;
     const int nsub = GW / n_eff;
     const int wslot = lane % n_eff, sub = lane / n_eff;
-    const bool has_w = wslot < n_in_chunk;
-    const int wpos = has_w ? chunk.x + wslot : 0;  // position in the launch's omega list
-    const int b = has_w ? A.act_idx[wpos] : 0;
+    const bool in_chunk = wslot < n_in_chunk;
+    const int wpos = in_chunk ? chunk.x + wslot : 0;  // position in the launch's omega list
+    const int b = in_chunk ? A.act_idx[wpos] : 0;
+    const bool has_w = in_chunk && !(A.skip_lost && A.status[b] != 0);  // (a lost matrix: see k_assemble_dense)
     cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
     if (has_w) {
         omega = mk(A.omega[b].x, A.omega[b].y);
@@ -459,9 +461,10 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     while (n_eff < n_in_chunk) n_eff <<= 1;
     const int nsub = GW / n_eff;
     const int wslot = lane % n_eff, sub = lane / n_eff;
-    const bool has_w = wslot < n_in_chunk;
-    const int wpos = has_w ? chunk.x + wslot : 0;  // position in the launch's omega list
-    const int b = has_w ? A.act_idx[wpos] : 0;
+    const bool in_chunk = wslot < n_in_chunk;
+    const int wpos = in_chunk ? chunk.x + wslot : 0;  // position in the launch's omega list
+    const int b = in_chunk ? A.act_idx[wpos] : 0;
+    const bool has_w = in_chunk && !(A.skip_lost && A.status[b] != 0);  // (a lost matrix: see k_assemble_dense)
     cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
     if (has_w) {
         omega = mk(A.omega[b].x, A.omega[b].y);
@@ -727,9 +730,10 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
     double2* slots = reinterpret_cast<double2*>(lds_raw + 3 * N + ((3 * N) & 1)) + group_in_block * (NSEL * GW * 3);
 
     const int2 chunk = A.chunks[blockIdx.y];
-    const bool has_w = lane < chunk.y;
-    const int wpos = has_w ? chunk.x + lane : 0;
-    const int b = has_w ? A.act_idx[wpos] : 0;
+    const bool in_chunk = lane < chunk.y;
+    const int wpos = in_chunk ? chunk.x + lane : 0;
+    const int b = in_chunk ? A.act_idx[wpos] : 0;
+    const bool has_w = in_chunk && !(A.skip_lost && A.status[b] != 0);  // (a lost matrix: see k_assemble_dense)
     cd omega = mk(0.0, 0.0), rdw = mk(0.0, 0.0);
     if (has_w) {
         omega = mk(A.omega[b].x, A.omega[b].y);
@@ -978,6 +982,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     A.domega = (const double2*)L.domega;
     A.intervals = L.intervals;
     A.status = L.status;
+    A.skip_lost = L.skip_lost;
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     const long nitems = (long)L.npairs * L.P.nm;
@@ -988,7 +993,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
     dim3 grid((unsigned)gx, (unsigned)nchunks), block(256);
     const size_t lds = ((size_t)3 * L.P.N + (size_t)A.geom.ni()) * sizeof(double);
     // electrostatic GK15 on folded records: the union-walk kernel (EMME_UNION=0: independent lanes)
-    static const bool union_walk = !(std::getenv("EMME_UNION") && atoi(std::getenv("EMME_UNION")) == 0);
+    const bool union_walk = L.union_walk != 0;
     if (L.gk_points == 15 && etab && union_walk && L.P.nm == 1) {
         const long ug = (nitems + L.items_per_group - 1) / L.items_per_group;
         long ugx = (ug + 15) / 16;
@@ -996,8 +1001,7 @@ hipError_t launch_assemble_cached(const AssembleLaunch& L, const NodeCacheGeom& 
         if (ugx > 65535) ugx = 65535;
         const size_t n0 = (size_t)3 * L.P.N;
         // intervals served per round (EMME_UNION_SEL, default 2): see the kernel
-        const char* sel_s = std::getenv("EMME_UNION_SEL");
-        const int nsel = sel_s ? std::atoi(sel_s) : 2;
+        const int nsel = L.union_sel;
         const size_t ulds0 = (n0 + (n0 & 1)) * sizeof(double);
         const size_t slot_bytes = (size_t)16 * 16 * 3 * sizeof(double2);
         if (nsel <= 1)
@@ -1051,6 +1055,7 @@ hipError_t launch_assemble_cached_em(const AssembleLaunch& L, const NodeCacheGeo
     A.domega = (const double2*)L.domega;
     A.intervals = L.intervals;
     A.status = L.status;
+    A.skip_lost = L.skip_lost;
     const int gw = L.gk_points == 15 ? 16 : 32;
     const int groups_per_block = 256 / gw;
     const long nitems = (long)L.npairs;  // an item is a pair

@@ -197,6 +197,7 @@ struct DenseArgs {
     int* status;
     unsigned long long* stats;  // [0] dense rounds, [1] sparse rounds, [2] sparse columns, [3] tile tasks
     int dense_min_cols;         // columns that must need an interval for the MFMA path
+    int skip_lost;              // columns whose matrix is already flagged (status) are left alone
 };
 
 // ---- the fill: level by level ----------------------------------------------------------------------
@@ -249,9 +250,13 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     const int waves_here = min(4, ntiles - (tile - wave));  // waves of this workgroup that own a tile
 
     const int2 ch = A.chunks[chunk];
-    const bool has_w = col < ch.y;
-    const int wpos = ch.x + (has_w ? col : 0);
+    const bool in_chunk = col < ch.y;
+    const int wpos = ch.x + (in_chunk ? col : 0);
     const int b = A.act_idx[wpos];
+    // A matrix that already holds a non-finite integral is lost (its chain retires at the next Newton step, as the
+    // reference's does: include/solver.h:142-153): nobody works on it any more.  (The four lanes of a column read
+    // the flag in one instruction: they agree.)
+    const bool has_w = in_chunk && !(A.skip_lost && A.status[b] != 0);
     const int cls = -copysign(1.0, A.omega[b].x) > 0.0 ? 0 : 1;
     // (everything the stores need is fetched again after the walk: nothing of it stays live in the loop)
     auto store = [&](int r, int c, cd v, cd rdw) {
@@ -729,8 +734,8 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.intervals = L.intervals;
     A.status = L.status;
     A.stats = stats;
-    const char* e = std::getenv("EMME_DENSE_MIN_COLS");
-    A.dense_min_cols = e ? std::atoi(e) : 3;
+    A.dense_min_cols = L.dense_min_cols;
+    A.skip_lost = L.skip_lost;
     const int ntiles = (L.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;
     hipLaunchKernelGGL(k_assemble_dense, dim3((unsigned)((long)ntg * A.nchunks)), dim3(256), 0, stream, A);

@@ -46,7 +46,7 @@ bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice;
 }
 
-enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2, K_DEFER = 3, K_CACHE = 4 };
+enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2, K_DEFER = 3, K_CACHE = 4, K_NULL = 5 };
 
 }  // namespace
 }  // namespace emme
@@ -72,8 +72,7 @@ struct emme_ctx {
     std::vector<int> h_chunks;
     std::vector<int> h_actidx; // its host image (kept alive across the async upload)
     int last_fill_mode = -1;   // kernel family of the last fill: 0 nodes, 1 omega-lane, 2 cached
-    int wl_min = 4;            // use the omega-lane kernel from this many active items on
-    int cache_min_batch = 8;   // build the node cache only for calls with at least this many omegas
+    emme_options_t opt{};      // per-context options (emme_options_t; environment overrides applied at creation)
     // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
     int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
     NodeCacheGeom cache_geom{};
@@ -117,7 +116,6 @@ struct emme_ctx {
     unsigned long long* d_worklist = nullptr;  // integrals deferred to the cooperative kernel
     unsigned int* d_worklist_count = nullptr;
     size_t worklist_cap = 0;
-    double cache_budget_gb = 176.0;  // both classes together (MI355X: 288 GB of HBM3E)
     int mat_cap = 0;  // matrices per set
     double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
     double* d_iterates = nullptr;
@@ -222,6 +220,80 @@ struct AllocTimer {
 
 size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
 
+void options_default(emme_options_t& o) {
+    o = emme_options_t{};
+    o.size = (int)sizeof(emme_options_t);
+    o.node_cache_gb = 176.0;  // both contour classes together (MI355X: 288 GB of HBM3E)
+    o.cache_min_batch = 8;
+    o.cache_min_depth = 0;
+    o.fill = EMME_FILL_AUTO;
+    o.phase_table = 1;
+    o.em_shared = 1;
+    o.wl_min = 4;
+    o.union_sel = 2;
+    o.union_ipg_few = 2, o.union_few_chunks = 3;
+    o.coop_wide_min = 4096;
+    o.defer_one_group = 0;
+    o.dense_min_cols = 3;
+    o.dense_min_tasks = 2000;
+    o.dense_cost_ratio = 4.0;
+    o.skip_lost = 1;
+    o.lu_split = 0;
+    o.lu_group_min_n = 256;
+    o.lu_spin_limit = 16000000;  // about 4 s
+    o.lu_unblocked = 0;
+}
+
+// The EMME_* environment variables: developer overrides, read ONCE per context (at creation), winning over
+// the caller's struct.  Library callers use emme_options_t.
+void options_env_overrides(emme_options_t& o) {
+    auto geti = [](const char* name, int& v) {
+        if (const char* e = std::getenv(name)) v = std::atoi(e);
+    };
+    auto getd = [](const char* name, double& v) {
+        if (const char* e = std::getenv(name)) v = std::atof(e);
+    };
+    getd("EMME_NODE_CACHE_GB", o.node_cache_gb);
+    geti("EMME_CACHE_MIN_BATCH", o.cache_min_batch);
+    geti("EMME_CACHE_MIN_DEPTH", o.cache_min_depth);
+    if (const char* e = std::getenv("EMME_DENSE"))
+        if (std::atoi(e) == 0 && o.fill == EMME_FILL_AUTO) o.fill = EMME_FILL_UNION;
+    if (const char* e = std::getenv("EMME_UNION"))
+        if (std::atoi(e) == 0) o.fill = EMME_FILL_LANES;
+    geti("EMME_PHASE_TABLE", o.phase_table);
+    geti("EMME_EM_SHARED", o.em_shared);
+    geti("EMME_WL_MIN", o.wl_min);
+    geti("EMME_UNION_SEL", o.union_sel);
+    geti("EMME_UNION_IPG_FEW", o.union_ipg_few);
+    geti("EMME_UNION_FEW_CHUNKS", o.union_few_chunks);
+    geti("EMME_COOP_WIDE_MIN", o.coop_wide_min);
+    if (std::getenv("EMME_DEFER_ONE_GROUP")) o.defer_one_group = 1;
+    geti("EMME_DENSE_MIN_COLS", o.dense_min_cols);
+    geti("EMME_DENSE_MIN_TASKS", o.dense_min_tasks);
+    getd("EMME_DENSE_COST_RATIO", o.dense_cost_ratio);
+    geti("EMME_SKIP_LOST", o.skip_lost);
+    geti("EMME_LU_SPLIT", o.lu_split);
+    if (const char* e = std::getenv("EMME_LU_GROUP")) o.lu_group_min_n = std::atoi(e) <= 0 ? -1 : std::atoi(e);
+    geti("EMME_LU_SPIN_LIMIT", o.lu_spin_limit);
+    if (std::getenv("EMME_LU_UNBLOCKED")) o.lu_unblocked = 1;
+}
+
+int options_check(const emme_options_t* o) {
+    if (o->size != (int)sizeof(emme_options_t)) {
+        set_error("emme_options_t: size field does not match this library (use emme_options_default)");
+        return EMME_EINVAL;
+    }
+    if (!(o->node_cache_gb >= 0.0) || o->cache_min_batch < 1 || o->cache_min_depth < 0 || o->fill < EMME_FILL_AUTO ||
+        o->fill > EMME_FILL_LANES || o->wl_min < 1 || (o->union_sel != 1 && o->union_sel != 2 && o->union_sel != 4) ||
+        o->union_ipg_few < 1 || o->union_few_chunks < 0 || o->coop_wide_min < -1 || o->dense_min_cols < 1 ||
+        o->dense_min_cols > 17 || o->dense_min_tasks < 0 || !(o->dense_cost_ratio > 0.0) || o->lu_split < 0 ||
+        o->lu_split > 16 || o->lu_spin_limit < 1) {
+        set_error("emme_options_t: value out of range");
+        return EMME_EINVAL;
+    }
+    return EMME_OK;
+}
+
 hipEvent_t get_event(emme_ctx* c) {
     if (!c->free_events.empty()) {
         hipEvent_t e = c->free_events.back();
@@ -267,6 +339,8 @@ int drain_spans(emme_ctx* c) {
             c->acc.deferred_ms += ms, c->acc.deferred_launches++;
         else if (s.kind == K_CACHE)
             c->acc.cache_build_ms += ms, c->acc.cache_build_launches++;
+        else if (s.kind == K_NULL)
+            c->acc.nullspace_ms += ms, c->acc.nullspace_launches++;
         else
             c->acc.other_ms += ms, c->acc.other_launches++;
         c->free_events.push_back(s.a);
@@ -339,9 +413,8 @@ int ensure_mats(emme_ctx* c, int nb, int sets) {
 // units each gets up to 8 workgroups (EMME_LU_SPLIT=k pins k; 1 = one workgroup per matrix).
 hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, const int* active,
                        double* tr, int* info, const int* h_active) {
-    static const bool force_unblocked = std::getenv("EMME_LU_UNBLOCKED") != nullptr;
-    const char* split_s = std::getenv("EMME_LU_SPLIT");  // read per call: the tests switch it
-    const int split_env = split_s ? std::atoi(split_s) : 0;
+    const bool force_unblocked = c->opt.lu_unblocked != 0;
+    const int split_env = c->opt.lu_split;
     // n <= ~560: the whole L21 panel fits in LDS; up to 1024 the chunked build takes over, which
     // needs helper workgroups (>= 2 per matrix, all resident); otherwise the unblocked kernel
     const bool fits = trace_solve_blocked_lds(n) <= 150 * 1024;
@@ -396,7 +469,7 @@ hipError_t trace_solve(emme_ctx* c, int n, int nbatch, double* A, double* B, con
             d_items = c->d_lu_items;
         }
         const hipError_t e = launch_trace_solve_blocked(n, nbatch, A, B, active, tr, info, nwg, d_items, n_live,
-                                                        c->d_lu_scratch, c->stream);
+                                                        c->d_lu_scratch, c->stream, c->opt.lu_group_min_n, c->opt.lu_spin_limit);
         if (e != hipErrorNotSupported) return e;
         (void)hipGetLastError();  // chunked build not possible here (one workgroup per matrix, or no room)
         c->last_lu_nwg = 1;
@@ -463,7 +536,7 @@ hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCach
 // exists.  Returns false (and disables the cache) if it does not fit the budget.
 bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->cache_depth == -2) return false;
-    const double budget = c->cache_budget_gb * (double)(1 << 30);
+    const double budget = c->opt.node_cache_gb * (double)(1 << 30);
     if (c->cache_depth == -1) {
         // full tree to depth dfull + the fixed subtree under the rightmost depth-5 node (that is
         // where ordinary damped roots refine); the largest that leaves half the budget free
@@ -475,8 +548,7 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
         // profiles/r02_size_sweep.jsonl): below that the context runs uncached (EMME_CACHE_MIN_DEPTH)
         // (tiled contexts: 6 -- their records are a third smaller, so depth 5 does fit at N = 1024, and is
         // as bad there: 97 omega-points/s)
-        const char* md = std::getenv("EMME_CACHE_MIN_DEPTH");
-        const int min_depth = md ? std::atoi(md) : (c->tiled ? 6 : 5);
+        const int min_depth = c->opt.cache_min_depth > 0 ? c->opt.cache_min_depth : (c->tiled ? 6 : 5);
         bool found = false;
         for (const auto& o : options) {
             if (o[0] < min_depth) break;
@@ -552,7 +624,7 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
     } else if (c->d_recs_ext[cls][k - 1]) {
         return;  // already there (the deferral was for an interval deeper than the subtree)
     }
-    const double budget = c->cache_budget_gb * (double)(1 << 30);
+    const double budget = c->opt.node_cache_gb * (double)(1 << 30);
     const size_t eb = cache_part_bytes(c, L.gk_points, g, k - 1);
     AllocTimer at(c);
     if (c->cache_bytes_used + (double)eb > budget ||
@@ -581,7 +653,7 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
 int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
                 const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
                 const double* d_domega, const unsigned long long* cost = nullptr,
-                const double* host_omega = nullptr) {
+                const double* host_omega = nullptr, bool newton_loop = false) {
     AssembleLaunch L;
     L.P = c->P;
     L.gk_points = c->p.integration_start_points;
@@ -598,6 +670,14 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     L.intervals = c->d_intervals;
     L.status = c->d_status;
     L.rounds = c->d_rounds;
+    // inside a root search a matrix that already holds a non-finite integral is lost (k_newton_update retires its
+    // chain): the fill kernels leave it alone.  Plain assembly calls always get the whole matrix.
+    L.skip_lost = newton_loop && c->opt.skip_lost != 0;
+    L.union_sel = c->opt.union_sel;
+    L.union_walk = c->opt.fill != EMME_FILL_LANES;
+    L.coop_wide_min = c->opt.coop_wide_min;
+    L.defer_one_group = c->opt.defer_one_group;
+    L.dense_min_cols = c->opt.dense_min_cols;
     std::vector<int>& idx = c->h_actidx;
     idx.clear();
     for (int b = 0; b < nbatch; ++b)
@@ -614,7 +694,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     // and pays off after ~10 fills: a call with a handful of omegas (a single root of a
     // parameter scan) goes through the on-the-fly kernels unless the cache already exists.
     bool use_cache = host_omega != nullptr && c->cache_depth != -2 &&
-                     (nbatch >= c->cache_min_batch || c->d_recs[0] != nullptr || c->d_recs[1] != nullptr);
+                     (nbatch >= c->opt.cache_min_batch || c->d_recs[0] != nullptr || c->d_recs[1] != nullptr);
     if (use_cache) {
         bool need[2] = {false, false};
         for (int b : idx) need[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1] = true;
@@ -675,8 +755,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         // the union-walk kernel (electrostatic GK15 on folded records, assemble_cached.hip): lanes
         // that sit a round out cost little there, so its chunks are always full and each group
         // takes three items (measured optimum: 86.5 ms vs 104 with the policy below)
-        static const bool union_env = !(std::getenv("EMME_UNION") && std::atoi(std::getenv("EMME_UNION")) == 0);
-        const bool union_walk = (union_env || c->tiled) && c->folded && c->nm == 1 && L.gk_points == 15;
+        const bool union_walk = (c->opt.fill != EMME_FILL_LANES || c->tiled) && c->folded && c->nm == 1 && L.gk_points == 15;
         // Omega chunks of unequal size.  Every lane walks ONE omega's trees, so an
         // omega whose integrals need 3x the intervals keeps its lane busy 3x longer than its
         // neighbours'.  A chunk of n omegas gives each of them gw/n lanes per group: expensive
@@ -699,11 +778,10 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             int dense_cap = gw;
             if (c->tiled) {
                 const long ntiles = (c->npairs + 15) / 16;
-                const char* tt = std::getenv("EMME_DENSE_MIN_TASKS");
-                const long min_tasks = tt ? std::atol(tt) : 2000;
+                const long min_tasks = c->opt.dense_min_tasks;
                 while (dense_cap > 2 && ((long)idx.size() + dense_cap - 1) / dense_cap * ntiles < min_tasks) dense_cap >>= 1;
             }
-            static const double dense_ratio = std::getenv("EMME_DENSE_COST_RATIO") ? std::atof(std::getenv("EMME_DENSE_COST_RATIO")) : 4.0;
+            const double dense_ratio = c->opt.dense_cost_ratio;
             size_t q = 0;
             while (q < idx.size()) {
                 int cap = c->tiled ? dense_cap : gw;
@@ -723,9 +801,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             // up to three chunks (late Newton steps: <= 48 omegas) leave the SIMDs short of waves
             // with three items per group: two then (measured: one is worse again -- every
             // workgroup stages the grid tables; EMME_UNION_IPG_FEW / EMME_UNION_FEW_CHUNKS)
-            const char* e1 = std::getenv("EMME_UNION_IPG_FEW");
-            const char* e2 = std::getenv("EMME_UNION_FEW_CHUNKS");
-            const int ipg_few = e1 ? std::atoi(e1) : 2, few = e2 ? std::atoi(e2) : 3;
+            const int ipg_few = c->opt.union_ipg_few, few = c->opt.union_few_chunks;
             if (nchunks <= few) L.items_per_group = std::max(1, ipg_few);
         }
         if (n_lane) {
@@ -849,7 +925,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                         dg[q] & 0x7fffffffffffffull);
             fprintf(stderr, "\n");
         }
-    } else if (n_act >= c->wl_min) {
+    } else if (n_act >= c->opt.wl_min) {
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
         {
@@ -875,11 +951,31 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
 extern "C" {
 
 const char* emme_last_error(void) { return g_error.c_str(); }
-int emme_version(void) { return 2; }
+int emme_version(void) { return 3; }
+
+void emme_options_default(emme_options_t* opt) {
+    if (opt) options_default(*opt);
+}
 
 int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
+    return emme_ctx_create_ex(p, device, nullptr, out);
+}
+
+int emme_ctx_create_ex(const emme_params_t* p, int device, const emme_options_t* opt, emme_ctx_t** out) {
     if (!p || !out) return EMME_EINVAL;
     *out = nullptr;
+    emme_options_t o;
+    options_default(o);
+    if (opt) {
+        const int rc = options_check(opt);
+        if (rc) return rc;
+        o = *opt;
+    }
+    options_env_overrides(o);
+    {
+        const int rc = options_check(&o);
+        if (rc) return rc;
+    }
     if (p->integration_start_points != 15 && p->integration_start_points != 31) {
         // include/functions.h:329
         set_error("integration_start_points should be 15 or 31");
@@ -908,9 +1004,7 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->p = *p;
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = std::getenv("EMME_WL_MIN")) c->wl_min = std::atoi(e);
-    if (const char* e = std::getenv("EMME_CACHE_MIN_BATCH")) c->cache_min_batch = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("EMME_NODE_CACHE_GB")) c->cache_budget_gb = std::atof(e);
+    c->opt = o;
     const int N = p->npoints;
     c->N = N;
     const bool es = std::fpclassify(p->beta_e) == FP_ZERO;  // include/solver.h:406-407
@@ -918,16 +1012,15 @@ int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out) {
     c->nm = es ? 1 : 3;
     // electromagnetic contexts share one node record per (pair, interval, node) between the three
     // moments (EMME_EM_SHARED=0: one record per moment, for A/B comparisons)
-    c->em_shared = !es && !(std::getenv("EMME_EM_SHARED") && std::atoi(std::getenv("EMME_EM_SHARED")) == 0);
-    // EMME_PHASE_TABLE=0: unfolded records and exp(A0 + T omega) per (pair, node, omega) in the fill
-    c->folded = !(std::getenv("EMME_PHASE_TABLE") && std::atoi(std::getenv("EMME_PHASE_TABLE")) == 0);
+    c->em_shared = !es && o.em_shared != 0;
+    // phase_table = 0: unfolded records and exp(A0 + T omega) per (pair, node, omega) in the fill
+    c->folded = o.phase_table != 0;
     // electrostatic GK15 on folded records: tiled record layout + dense fill on the FP64 matrix cores
     // (assemble_dense.hip) instead of the union walk (EMME_DENSE=0 restores that).  It
     // carries the safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature goal
     // (integration_accuracy) is tighter than 1e-9 keep the exact union kernel.
     c->tiled = es && p->integration_start_points == 15 && c->folded && p->integration_accuracy >= 1e-9 &&
-               !(std::getenv("EMME_DENSE") && std::atoi(std::getenv("EMME_DENSE")) == 0) &&
-               !(std::getenv("EMME_UNION") && std::atoi(std::getenv("EMME_UNION")) == 0);
+               o.fill == EMME_FILL_AUTO;
 
     DevParams& P = c->P;
     std::vector<double> tab(3 * (size_t)N);
@@ -1011,6 +1104,36 @@ void emme_ctx_destroy(emme_ctx_t* c) {
 }
 
 void emme_release_pooled_memory(void) { pool_release_all(); }
+
+int emme_ctx_set_options(emme_ctx_t* c, const emme_options_t* opt) {
+    if (!c || !opt) return EMME_EINVAL;
+    const int rc = options_check(opt);
+    if (rc) return rc;
+    const bool layout_differs = opt->fill != c->opt.fill || (opt->phase_table != 0) != (c->opt.phase_table != 0) ||
+                                (opt->em_shared != 0) != (c->opt.em_shared != 0);
+    if (layout_differs) {
+        if (c->d_recs[0] || c->d_recs[1]) {
+            set_error("emme_ctx_set_options: fill / phase_table / em_shared fix the layout of the node cache, which exists already");
+            return EMME_EINVAL;
+        }
+        const bool es = c->nm == 1;
+        c->em_shared = !es && opt->em_shared != 0;
+        c->folded = opt->phase_table != 0;
+        c->tiled = es && c->p.integration_start_points == 15 && c->folded && c->p.integration_accuracy >= 1e-9 &&
+                   opt->fill == EMME_FILL_AUTO;
+    }
+    if (opt->node_cache_gb > 0.0 && c->cache_depth == -2 && !c->d_recs[0] && !c->d_recs[1])
+        c->cache_depth = -1;  // a budget after "no cache": decide again
+    if (opt->lu_split != c->opt.lu_split) c->lu_one_wg = false;
+    c->opt = *opt;
+    return EMME_OK;
+}
+
+int emme_ctx_get_options(const emme_ctx_t* c, emme_options_t* opt) {
+    if (!c || !opt) return EMME_EINVAL;
+    *opt = c->opt;
+    return EMME_OK;
+}
 
 int emme_ctx_set_stream(emme_ctx_t* c, void* s) {
     if (!c) return EMME_EINVAL;
@@ -1347,13 +1470,13 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         }
         return EMME_OK;
     };
-    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_Mold, nullptr, nullptr, nullptr, nullptr, w0.data());
+    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_Mold, nullptr, nullptr, nullptr, nullptr, w0.data(), true);
     if (rc) return rc;
     rc = refresh_cost();  // synchronises; the first fill's interval counts order the second
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_omega, w1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
-                     cost.data(), w1.data());
+                     cost.data(), w1.data(), true);
     if (rc) return rc;
 
     rc = refresh_cost();
@@ -1407,7 +1530,8 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         {
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(launch_newton_update(n, c->d_tr, c->d_omega, c->d_domega, c->d_active, c->d_iters,
-                                         c->d_info, tol, c->d_iterates, j, stride, c->stream, c->p_w));
+                                         c->d_info, tol, c->d_iterates, j, stride, c->stream, c->p_w,
+                                         c->opt.skip_lost ? c->d_status : nullptr));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::copy(c->p_w, c->p_w + 2 * (size_t)n, h_w.begin());
@@ -1418,7 +1542,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             if (!any) break;  // (this step's LU and update found nothing active: no-ops)
         }
         rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
-                         cost.data(), h_w.data());
+                         cost.data(), h_w.data(), true);
         if (rc) return rc;
         {
             ScopedSpan s(c, K_OTHER);
@@ -1485,6 +1609,91 @@ int emme_bessel_batch(const double* z, int n, double* out) {
     HIP_TRY(hipMemcpy(dz, z, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     HIP_TRY(launch_bessel_probe(dz, n, dout, nullptr));
     HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 8 * n, hipMemcpyDeviceToHost));
+    return EMME_OK;
+}
+
+// nullSpace (reference include/solver.h:58-112), batched on the device: see nullspace.hip
+int emme_null_vectors_batch(emme_ctx_t* c, int n, int nbatch, const double* M, double* vecs, int* info) {
+    if (!c || !vecs || !info || n < 1 || nbatch < 1) return EMME_EINVAL;
+    if (!M && (n != c->dim || nbatch > c->last_n || !c->d_M)) {
+        set_error("emme_null_vectors_batch: M = NULL needs a preceding emme_solve_roots call (n = emme_ctx_dim, nbatch <= its n)");
+        return EMME_EINVAL;
+    }
+    if (n > 2048) {
+        set_error("emme_null_vectors_batch: order above 2048 is not supported");
+        return EMME_ECONFIG;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_batch(c, nbatch);
+    if (rc) return rc;
+    const size_t mbytes = (size_t)n * n * 2 * sizeof(double);
+    struct Tmp {  // device scratch of this call, released on every way out
+        double *a = nullptr, *b = nullptr, *v = nullptr;
+        int *info = nullptr, *maps = nullptr;
+        ~Tmp() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            if (v) (void)hipFree(v);
+            if (info) (void)hipFree(info);
+            if (maps) (void)hipFree(maps);
+        }
+    } t;
+    // work copy the factorisation overwrites: the context's LU work set after a root search, else a buffer of its own
+    double* work = nullptr;
+    if (!M && c->d_work && c->mat_cap >= nbatch) {
+        work = c->d_work;
+        HIP_TRY(hipMemcpyAsync(work, c->d_M, mbytes * nbatch, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIP_TRY(malloc_retry((void**)&t.a, mbytes * nbatch));
+        work = t.a;
+        const double* src = M ? M : c->d_M;
+        HIP_TRY(hipMemcpyAsync(work, src, mbytes * nbatch, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(malloc_retry((void**)&t.v, sizeof(double) * 2 * (size_t)n * nbatch));
+    HIP_TRY(malloc_retry((void**)&t.info, sizeof(int) * nbatch));
+    const bool one_wg = trace_solve_blocked_lds(n) <= 150 * 1024;  // the whole L21 panel in one workgroup's LDS
+    const int max_sweeps = 8;
+    if (one_wg || n <= 1024) {
+        // blocked factorisations: row orders in the LU scratch.  Above the one-workgroup panel the chunked
+        // multi-workgroup kernel of the Newton step factors (two workgroups per matrix, which must be resident
+        // together: slices of at most half the compute units; its right-hand side is a dummy).
+        const int slice_max = one_wg ? nbatch : std::max(1, c->n_cu / 2);
+        const size_t need = trace_solve_blocked_scratch(n, std::min(nbatch, slice_max));
+        if (need > c->lu_scratch_bytes) {
+            if (c->d_lu_scratch) (void)hipFree(c->d_lu_scratch);
+            c->d_lu_scratch = nullptr, c->lu_scratch_bytes = 0;
+            HIP_TRY(malloc_retry(&c->d_lu_scratch, need));
+            c->lu_scratch_bytes = need;
+        }
+        if (!one_wg) HIP_TRY(malloc_retry((void**)&t.b, mbytes * std::min(nbatch, slice_max)));
+        for (int b0 = 0; b0 < nbatch; b0 += slice_max) {
+            const int nb = std::min(slice_max, nbatch - b0);
+            double* a0 = work + (size_t)b0 * n * n * 2;
+            ScopedSpan sp(c, K_NULL);
+            if (one_wg) {
+                HIP_TRY(launch_lu_inplace(n, nb, a0, nullptr, nb, c->d_info, c->d_lu_scratch, c->stream));
+            } else {
+                HIP_TRY(hipMemsetAsync(t.b, 0, mbytes * nb, c->stream));
+                const hipError_t e = launch_trace_solve_blocked(n, nb, a0, t.b, nullptr, c->d_tr, c->d_info, 2, nullptr, nb,
+                                                                c->d_lu_scratch, c->stream, -1, c->opt.lu_spin_limit);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("emme_null_vectors_batch: the chunked factorisation could not be launched (its two workgroups per matrix must be resident together)");
+                    return EMME_EDEVICE;
+                }
+            }
+            HIP_TRY(launch_null_iterate(n, a0, trace_solve_rowmaps(c->d_lu_scratch, n, nb), trace_solve_nb(), nullptr, nb,
+                                        c->d_info, t.v + (size_t)b0 * n * 2, t.info + b0, max_sweeps, c->stream));
+        }
+    } else {
+        HIP_TRY(malloc_retry((void**)&t.maps, sizeof(int) * (size_t)n * nbatch));
+        ScopedSpan sp(c, K_NULL);
+        HIP_TRY(launch_lu_unblocked_inplace(n, nbatch, work, t.maps, c->d_info, c->stream));
+        HIP_TRY(launch_null_iterate(n, work, t.maps, n, nullptr, nbatch, c->d_info, t.v, t.info, max_sweeps, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(vecs, t.v, sizeof(double) * 2 * (size_t)n * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(info, t.info, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return EMME_OK;
 }
 

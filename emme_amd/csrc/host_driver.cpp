@@ -5,9 +5,9 @@
 // generator with its two-direction sweep and 0.01*step fuzz (:139-172), filter_input
 // (:174-180), the scan loop with omega continuation and the NaN fall-back (:223-325), the
 // output.json schema (:208-221, 246-262, 270-321) and the raw eigenMatrics/<key>Eq<v>.bin files
-// (:255-257, 295-299, 61-63).  nullSpace (include/solver.h:58-112) is replaced by inverse
-// iteration on M^H M with a partial-pivot LU: same vector as the SVD's last right singular
-// vector, up to the arbitrary complex phase LAPACK would return.
+// (:255-257, 295-299, 61-63).  nullSpace (include/solver.h:58-112) runs on the device
+// (emme_null_vectors_batch, nullspace.hip); the host version below (inverse iteration on M^H M with a
+// partial-pivot LU of a complex SYMMETRIC M) is emme_null_vector: a second opinion for tests and tools.
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -167,21 +167,25 @@ JsonValue solve_once(const JsonValue& input, cplx& omega, const std::string& mat
                          nullptr) != EMME_OK)
         throw std::runtime_error(emme_last_error());
     if (info > 0) {
-        // include/solver.h:142-153
+        // include/solver.h:142-153.  The reference prints zsysv's index of the singular block of its LDL^T
+        // factorisation; the step here is a partial-pivot LU, whose index of the zero pivot is a different
+        // number for the same verdict: the reference's sentence without a number it would not print, and
+        // this library's index marked as such.
         std::ostringstream oss;
         oss << "Linear solve failed. The factorization has been completed, but the "
-            << "block diagonal matrix D is exactly singular at " << info
-            << ", so the solution could not be computed.";
+            << "block diagonal matrix D is exactly singular"
+            << ", so the solution could not be computed. [emme_amd: partial-pivot LU, zero pivot in column " << info << "]";
         throw std::runtime_error(oss.str());
     }
     if (info < 0) {
         // Failures the reference does not have a code for.  It would carry a non-finite integral
-        // into omega and end with a NaN eigenvalue, or (singular LAPACK step) throw; either way the
-        // scan records {"eigenvalue":"NaN","reason":...} (src/main.cpp:311-318) and does NOT
+        // into M, where zsysv fails (the message above), or into omega and end with a NaN eigenvalue;
+        // either way the scan records {"eigenvalue":"NaN","reason":...} (src/main.cpp:311-318) and does NOT
         // continue the next scan point from this omega.  Same here.
         throw std::runtime_error(
             info == EMME_ENUMERIC
-                ? "Integration failed: non-finite integral or quadrature depth cap reached (EMME_ENUMERIC)."
+                ? "Linear solve failed. The matrix holds a non-finite integral, or the quadrature depth cap was reached "
+                  "(EMME_ENUMERIC), so the solution could not be computed."
                 : "Linear solve failed on the device (EMME_EDEVICE).");
     }
     const int dim = emme_ctx_dim(ctx);
@@ -194,7 +198,10 @@ JsonValue solve_once(const JsonValue& input, cplx& omega, const std::string& mat
         f.write(reinterpret_cast<const char*>(M.data()), (std::streamsize)(sizeof(cplx) * M.size()));
         file_ok = (bool)f;
     }
-    null_vector_of(M.data(), dim, vec.data());
+    // nullSpace (include/solver.h:58-112, src/main.cpp:73-76) on the device, from M(omega_final) as the search left it
+    int vinfo = 0;
+    if (emme_null_vectors_batch(ctx, dim, 1, nullptr, reinterpret_cast<double*>(vec.data()), &vinfo) != EMME_OK)
+        throw std::runtime_error(emme_last_error());
     JsonValue res = JsonValue::make_object();
     JsonValue ev = JsonValue::make_array();
     ev.items.push_back(JsonValue::make(root[0]));

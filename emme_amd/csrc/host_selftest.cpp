@@ -30,6 +30,7 @@ void emme_ctx_destroy(emme_ctx_t*) {}
 int emme_ctx_dim(const emme_ctx_t*) { return EMME_EINVAL; }
 int emme_solve_roots(emme_ctx_t*, const double*, int, double, int, double*, int*, int*, double*) { return EMME_EDEVICE; }
 int emme_ctx_get_matrix(emme_ctx_t*, int, double*) { return EMME_EDEVICE; }
+int emme_null_vectors_batch(emme_ctx_t*, int, int, const double*, double*, int*) { return EMME_EDEVICE; }
 }
 
 static int failures = 0;

@@ -34,6 +34,13 @@ struct AssembleLaunch {
     unsigned long long* intervals;  // device or null
     int* status;         // device
     unsigned long long* rounds = nullptr;  // device [1], omega-lane kernel diagnostic
+    // per-context options (include/emme_hip.h: emme_options_t)
+    int skip_lost = 0;         // skip integrals of a matrix whose status flag is already set (Newton loop only)
+    int union_sel = 2;         // union walk: intervals served per round
+    int union_walk = 1;        // electrostatic GK15 on folded records: union-walk kernel (0: independent lanes)
+    int coop_wide_min = 4096;  // deferred list: length from which the one-wave cooperative kernel takes over (-1 never)
+    int defer_one_group = 0;   // deferred integrals by one lane group each
+    int dense_min_cols = 3;    // dense fill: columns that must need an interval for the MFMA path
 };
 // lanes-are-nodes kernel; with a node cache (g != null) it reads cached records where they exist
 hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const NodeCacheGeom* g = nullptr,
@@ -121,7 +128,24 @@ size_t trace_solve_chunked_lds(int n);  // 560 < n <= 1024: panel rows in chunks
 size_t trace_solve_blocked_scratch(int n, int nbatch);
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
                                       double* tr, int* info, int nwg, const int* items, int nitems,
-                                      void* scratch, hipStream_t stream);
+                                      void* scratch, hipStream_t stream, int group_min_n = 256, int spin_limit = 0);
+
+// ---- nullSpace (nullspace.hip): factorisation alone + inverse iteration --------------------------------
+// P A = L U in place (multipliers left of the pivots, rows never moved), no right-hand sides; for orders whose
+// panel fits one workgroup's LDS (hipErrorNotSupported otherwise).  scratch as for launch_trace_solve_blocked.
+hipError_t launch_lu_inplace(int n, int nbatch, double* A, const int* items, int nitems, int* info, void* scratch,
+                             hipStream_t stream);
+int trace_solve_nb();  // rows per panel = rows per row-order snapshot of the blocked factorisations
+// row-order snapshots inside a blocked factorisation's scratch: logical row x of matrix b is physical row
+// maps[(b ceil(n / nb) + x / nb) n + x]
+const int* trace_solve_rowmaps(const void* scratch, int n, int nbatch);
+// any order up to ~8000: unblocked, slow; maps [nbatch][n] receives the row order (one snapshot, nb = n)
+hipError_t launch_lu_unblocked_inplace(int n, int nbatch, double* A, int* maps, int* info, hipStream_t stream);
+size_t null_iterate_lds(int n);
+// right singular vector of the smallest singular value of every matrix, from its in-place LU: vecs [nbatch][n]
+// complex, info 0 / lu_info's code / EMME_ENUMERIC for a non-finite result
+hipError_t launch_null_iterate(int n, const double* A_lu, const int* rowmaps, int nb, const int* items, int nitems,
+                               const int* lu_info, double* vecs, int* info, int max_sweeps, hipStream_t stream);
 
 // QR-secant form of the step (linstep_qr.hip, reference include/solver.h:210-383): Wt holds the
 // TRANSPOSE of each matrix (destroyed), Mp the secant derivative (read only); writes
@@ -138,7 +162,8 @@ hipError_t launch_transpose(int n, int nbatch, const double* in, double* out, co
 hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,
                                 int* active, int* iters, const int* info, double tol,
                                 double* iterates, int iter_index, int iter_stride,
-                                hipStream_t stream, double* pub_omega = nullptr /* pinned host, all omegas */);
+                                hipStream_t stream, double* pub_omega = nullptr /* pinned host, all omegas */,
+                                const int* lost = nullptr /* status flags: a flagged chain retires with EMME_ENUMERIC */);
 
 // active == 2 ("converged, last step done") -> 0; pub_* (pinned host, nullable): the flags, the interval
 // counters and the deferred-integral count for the host to read after its next synchronisation

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(LU_THREADS) void k_trace_solve(int n, double2* A, d
 
 __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, double2* domega,
                                 int* active, int* iters, const int* info, double tol,
-                                double2* iterates, int iter_index, int iter_stride, double2* pub_omega) {
+                                double2* iterates, int iter_index, int iter_stride, double2* pub_omega,
+                                int* info_w, const int* lost) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbatch) return;
     if (active && active[b] == 0) {
@@ -168,9 +169,18 @@ __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, d
     }
     // d_eigen_value = -1 / trace; eigen_value += d (include/solver.h:139-140)
     const cd t = mk(tr[b].x, tr[b].y);
-    const cd d = -rcp(t);
+    cd d = -rcp(t);
     cd w = mk(omega[b].x, omega[b].y);
     w = w + d;
+    // a chain whose matrix holds a non-finite integral (or met the quadrature caps) is lost: the fill stopped
+    // working on that matrix when the flag went up, so what the factorisation saw is unspecified -- the chain
+    // retires here, at the step the reference's zsysv fails at (include/solver.h:142-153), with EMME_ENUMERIC
+    const bool is_lost = lost && active && lost[b] != 0;
+    if (is_lost) {
+        d = mk(__builtin_nan(""), __builtin_nan(""));
+        w = d;
+        info_w[b] = -6;
+    }
     omega[b] = make_double2(w.x, w.y);
     domega[b] = make_double2(d.x, d.y);
     if (iters) iters[b] += 1;
@@ -183,7 +193,7 @@ __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, d
         // The reassembly at the new omega still happens this step (solver.h:157), so the
         // flag only takes effect from the next step on: encoded as 2 = "last step".
         const bool conv = hypot(d.x, d.y) < hypot(tol * w.x, tol * w.y);
-        const bool fail = info && info[b] != 0;
+        const bool fail = is_lost || (info && info[b] != 0);
         if (fail)
             active[b] = 0;
         else if (conv || !(isfinite(w.x) && isfinite(w.y)))
@@ -260,10 +270,11 @@ hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int
 hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, double* domega,
                                 int* active, int* iters, const int* info, double tol,
                                 double* iterates, int iter_index, int iter_stride,
-                                hipStream_t stream, double* pub_omega) {
+                                hipStream_t stream, double* pub_omega, const int* lost) {
     hipLaunchKernelGGL(k_newton_update, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch,
                        (const double2*)tr, (double2*)omega, (double2*)domega, active, iters, info,
-                       tol, (double2*)iterates, iter_index, iter_stride, (double2*)pub_omega);
+                       tol, (double2*)iterates, iter_index, iter_stride, (double2*)pub_omega,
+                       const_cast<int*>(info), lost);
     return hipGetLastError();
 }
 

@@ -1335,7 +1335,86 @@ __global__ __launch_bounds__(BT) void k_trace_solve_grouped(int n, int nbatch, d
     }
 }
 
+// The factorisation alone (nullSpace, nullspace.hip): role 0's forward sweep of k_trace_solve_grouped on A only --
+// factor_panel, the rest of the group's columns, apply_group behind the group -- with no right-hand sides, no
+// helper workgroups and therefore no waits.  Leaves P A = L U in place (multipliers left of the pivots, every
+// row where it was) and the row order in the panel snapshots: logical row x = physical row snap[(x / NB) n + x].
+__global__ __launch_bounds__(BT) void k_lu_inplace(int n, double2* A, const int* items, int* info_out, SplitCtl ctl) {
+    extern __shared__ double2 lds2[];
+    __shared__ int s_info;
+    const int b = items ? items[blockIdx.x] : blockIdx.x;
+    int* flag_pub = ctl.flags + 8 * b;
+    int* snap = ctl.rowmaps + (size_t)b * ((n + NB - 1) / NB) * n;
+    double2* a = A + (size_t)b * n * n;
+    double2* bnone = a;  // (no right-hand sides: every column range below ends at n, the pointer is never followed)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* rowmap = reinterpret_cast<int*>(lds2);
+    double2* L11 = lds2 + (3 * n * (int)sizeof(int) + 15) / 16;
+    double2* panel = L11 + NB * NB + NB;
+    for (int r = tid; r < n; r += BT) rowmap[r] = r;
+    if (tid == 0) s_info = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nbk = min(NB, n - k0);
+        const int inf = factor_panel(n, a, k0, snap, flag_pub);
+        if (inf != 0) {  // uniform
+            if (tid == 0) s_info = inf;
+            break;
+        }
+        const int J0 = k0 + nbk;
+        const int gend = min(n, (k0 / GK) * GK + GK);
+        if (gend > J0) {
+            pivot_rows_update(n, a, bnone, rowmap, L11, k0, nbk, J0, gend, wave, lane);
+            __syncthreads();
+            mfma_update<false>(n, a, bnone, rowmap, panel, k0 + nbk, n - k0 - nbk, k0, nbk, J0, gend - J0, wave, lane);
+            __syncthreads();
+        }
+        if (J0 == gend && gend < n) {
+            const int g0 = (k0 / GK) * GK;
+            apply_group(n, a, bnone, g0, gend - g0, gend, n);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) info_out[b] = s_info;
+}
+
 }  // namespace
+
+int trace_solve_nb() { return NB; }
+
+// P A = L U in place for the matrices listed in `items` (device list of nitems batch indices, null = 0 .. nitems-1),
+// no right-hand sides: for nullSpace.  n must fit the one-workgroup panel (trace_solve_blocked_lds(n) <= 150 KB);
+// scratch as for launch_trace_solve_blocked (row orders: trace_solve_rowmaps()).
+hipError_t launch_lu_inplace(int n, int nbatch, double* A, const int* items, int nitems, int* info, void* scratch,
+                             hipStream_t stream) {
+    const size_t lds = trace_solve_blocked_lds(n);
+    if (lds > 150 * 1024) return hipErrorNotSupported;
+    static thread_local int attr_dev = -1;
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (attr_dev != cur_dev) {
+        (void)hipFuncSetAttribute((const void*)k_lu_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_dev = cur_dev;
+    }
+    SplitCtl ctl{};
+    ctl.nwg = 1;
+    ctl.spin_limit = 1;
+    ctl.items = items;
+    ctl.nitems = nitems;
+    ctl.diag = (double2*)scratch;
+    ctl.flags = (int*)(ctl.diag + (size_t)nbatch * n);
+    ctl.rowmaps = ctl.flags + 8 * (size_t)nbatch;
+    hipLaunchKernelGGL(k_lu_inplace, dim3(nitems), dim3(BT), lds, stream, n, (double2*)A, items, info, ctl);
+    return hipGetLastError();
+}
+
+// where the row orders of a factorisation live inside `scratch` (see trace_solve_blocked_scratch): per matrix
+// ceil(n / NB) snapshots of n ints; logical row x of matrix b = physical row maps[(b nblk + x / NB) n + x]
+const int* trace_solve_rowmaps(const void* scratch, int n, int nbatch) {
+    const double2* diag = (const double2*)scratch;
+    const int* flags = (const int*)(diag + (size_t)nbatch * n);
+    return flags + 8 * (size_t)nbatch;
+}
 
 // LDS of the chunked build (560 < n <= 1024): the panel holds RC rows at a time
 size_t trace_solve_chunked_lds(int n) {
@@ -1377,7 +1456,7 @@ static void lu_stamps_report(hipStream_t) {}
 
 hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, const int* active,
                                       double* tr, int* info, int nwg, const int* items, int nitems,
-                                      void* scratch, hipStream_t stream) {
+                                      void* scratch, hipStream_t stream, int group_min_n, int spin_limit) {
     // matrices whose whole L21 panel does not fit in LDS go through the chunked build, which
     // exists only with helper workgroups (the multipliers must be in global memory anyway)
     const bool chunk = trace_solve_blocked_lds(n) > 150 * 1024;
@@ -1417,14 +1496,10 @@ hipError_t launch_trace_solve_blocked(int n, int nbatch, double* A, double* B, c
             ctl.a_cut[i] = std::min(n, ((int)(lo * n) + 8) / 16 * 16);
         }
     }
-    {
-        const char* e = std::getenv("EMME_LU_SPIN_LIMIT");
-        ctl.spin_limit = e ? std::max(1, std::atoi(e)) : SPIN_LIMIT;
-    }
+    ctl.spin_limit = spin_limit > 0 ? spin_limit : SPIN_LIMIT;
     // grouped trailing updates (a quarter of the passes over the matrix): without look-ahead, from the
     // order at which it pays (n = 256, 128 matrices: 1.44 -> 1.34 ms; EMME_LU_GROUP=0 switches it off, =n sets the order)
-    int group_min_n = 256;
-    if (const char* e = std::getenv("EMME_LU_GROUP")) group_min_n = std::atoi(e) <= 0 ? (1 << 30) : std::atoi(e);
+    if (group_min_n <= 0) group_min_n = 1 << 30;  // (options: lu_group_min_n, -1 = never)
     const bool group = !chunk && nwg > 1 && ctl.na == 0 && n >= group_min_n;
     ctl.items = items;
     ctl.nitems = items ? nitems : nbatch;

@@ -67,11 +67,48 @@ typedef struct emme_profile {
     long long sparse_rounds;  /* served on the vector ALU, one omega column at a time      */
     long long sparse_columns;
     long long tile_tasks;
+    double nullspace_ms;      /* nullSpace: factorisation + inverse iteration launches (version 3) */
+    long nullspace_launches;
 } emme_profile_t;
+
+/* Per-context options (version 3).  emme_options_default() fills in what emme_ctx_create uses; a caller
+ * changes what it needs and passes the struct to emme_ctx_create_ex / emme_ctx_set_options.  The EMME_*
+ * environment variables of earlier versions remain as DEVELOPER overrides only: they are read once, when a
+ * context is created, and win over the struct (DESIGN.md appendix lists them). */
+#define EMME_FILL_AUTO 0   /* dense (matrix-core) fill where it applies, else union walk / independent lanes */
+#define EMME_FILL_UNION 1  /* never the dense fill: 48-byte records, union-walk kernel (electrostatic GK15)   */
+#define EMME_FILL_LANES 2  /* independent lanes on 48-byte records                                            */
+typedef struct emme_options {
+    int size;                 /* sizeof(emme_options_t) of the caller (set by emme_options_default)      */
+    /* ---- HBM node cache ---- */
+    double node_cache_gb;     /* budget, both contour classes together (176); 0: never build one         */
+    int cache_min_batch;      /* build the cache only for calls with at least this many omegas (8)       */
+    int cache_min_depth;      /* shallowest full tree worth caching; 0 = 6 (tiled layout) / 5            */
+    /* ---- fill routing (layout options are fixed once the context exists) ---- */
+    int fill;                 /* EMME_FILL_*                                                             */
+    int phase_table;          /* 1: folded records + per-launch phase table; 0: unfolded records         */
+    int em_shared;            /* 1: electromagnetic contexts share one record per pair between moments   */
+    int wl_min;               /* smallest uncached batch that takes the omega-lane kernel (4)            */
+    int union_sel;            /* union walk: intervals a lane group serves per round (1, 2, 4)           */
+    int union_ipg_few, union_few_chunks;  /* union walk: items per lane group in launches of few chunks  */
+    int coop_wide_min;        /* deferred-list length from which the one-wave cooperative kernel takes over; -1 never */
+    int defer_one_group;      /* 1: deferred integrals by one lane group each                            */
+    int dense_min_cols;       /* dense fill: omega columns that must need an interval for the MFMA path   */
+    int dense_min_tasks;      /* dense fill: chunk capacity is halved while a launch has fewer tile tasks */
+    double dense_cost_ratio;  /* dense fill: a chunk ends where an omega costs less than 1/ratio of its first */
+    int skip_lost;            /* 1: integrals of a matrix that already holds a non-finite entry are skipped */
+    /* ---- Newton linear step ---- */
+    int lu_split;             /* workgroups per matrix: 0 = by live matrices and order, k = k             */
+    int lu_group_min_n;       /* smallest order that takes the grouped trailing updates (256); -1 never   */
+    int lu_spin_limit;        /* polls before a hand-over wait of the multi-workgroup LU gives up         */
+    int lu_unblocked;         /* 1: the unblocked LU                                                      */
+} emme_options_t;
 
 const char* emme_last_error(void);
 int emme_params_sizeof(void);
-int emme_version(void); /* 2: emme_profile_t grew the cache_* fields; emme_comm_*, emme_gather_roots */
+int emme_version(void); /* 3: emme_options_t, emme_ctx_create_ex / _set_options / _get_options, emme_null_vectors_batch,
+                           emme_profile_t grew nullspace_*; 2: cache_* fields, emme_comm_*, emme_gather_roots */
+void emme_options_default(emme_options_t* opt);
 
 /* JSON text -> raw + derived parameters.  Reproduces the reference parser's grammar
  * (a number token is a float only if it contains '.', else atoi; no string escapes)
@@ -94,6 +131,12 @@ int emme_bessel_batch(const double* z, int n, double* out);
 
 /* One context per (device, parameter set). device < 0 => current device. */
 int emme_ctx_create(const emme_params_t* p, int device, emme_ctx_t** out);
+/* The same with options (NULL = defaults).  EMME_EINVAL for a struct of the wrong size or values out of range. */
+int emme_ctx_create_ex(const emme_params_t* p, int device, const emme_options_t* opt, emme_ctx_t** out);
+/* Change the options of a live context.  Everything takes effect from the next call on, except what fixes the
+ * layout of the node cache (fill, phase_table, em_shared): EMME_EINVAL if those differ once a cache exists. */
+int emme_ctx_set_options(emme_ctx_t* ctx, const emme_options_t* opt);
+int emme_ctx_get_options(const emme_ctx_t* ctx, emme_options_t* opt);
 void emme_ctx_destroy(emme_ctx_t* ctx);
 /* The node-cache buffers of destroyed contexts (up to ~170 GB) are kept in a process-wide pool
  * and reused by the next context (allocating them costs seconds, a parameter sweep creates one
@@ -171,6 +214,13 @@ int emme_ctx_get_matrix(emme_ctx_t* ctx, int b, double* M_host);
  * singular value of the n x n complex matrix M (row-major), by inverse iteration on M^H M.
  * Same vector as the reference's SVD result up to the arbitrary complex phase. Host pointers. */
 int emme_null_vector(const double* M, int n, double* vec /* 2n doubles */);
+/* The same on the device, batched (nullspace.hip): ONE partial-pivot LU per matrix (the Newton step's kernels,
+ * no right-hand sides) and inverse iteration v <- M^-1 (M^-H v) on its factors until the direction stops
+ * moving.  M: nbatch*n*n complex, row-major, host or device, not modified; NULL = the matrices M(omega_final)
+ * of the last emme_solve_roots call on this context (then n = emme_ctx_dim, nbatch <= that call's n).
+ * vecs: nbatch*n complex (host), unit 2-norm, arbitrary phase.  info (host, nbatch): 0, k > 0 = column k of the
+ * factorisation is exactly zero (no vector: NaN), EMME_ENUMERIC = non-finite result.  n <= 2048. */
+int emme_null_vectors_batch(emme_ctx_t* ctx, int n, int nbatch, const double* M, double* vecs, int* info);
 
 /* The reference's driver (src/main.cpp:182-338) on an input.json TEXT: one solve, or a
  * parameter scan over every key written {head, step, tail}, with omega continuation.

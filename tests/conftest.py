@@ -36,5 +36,6 @@ def emme():
     emme_amd.load()
     # the product builds its node cache only for calls with >= 8 omegas; the parity tests use a
     # handful and must still go through the cached kernels (the policy itself is tested separately)
-    os.environ.setdefault("EMME_CACHE_MIN_BATCH", "1")
+    # (a Python-side default merged into every Context the tests create -- emme_options_t, not the environment)
+    emme_amd.set_default_options(cache_min_batch=1)
     return emme_amd

@@ -15,8 +15,8 @@ TOL_M = 1e-10
 TOL_W = 1e-9
 
 
-def _ctx(emme, d):
-    return emme.Context(emme.params_from_dict(d))
+def _ctx(emme, d, **options):
+    return emme.Context(emme.params_from_dict(d), **options)
 
 
 @pytest.mark.parametrize("n", [16, 64])
@@ -276,7 +276,7 @@ def test_trace_solve_sizes_against_lapack(emme, n):
 @pytest.mark.parametrize("n,nwg", [(256, 2), (256, 4), (200, 3), (130, 2), (37, 2), (512, 4), (16, 8),
                                    (256, 6), (200, 7), (512, 8), (100, 5), (600, 2), (777, 5), (1024, 8),
                                    (512, 12), (300, 16), (900, 13)])
-def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
+def test_trace_solve_several_workgroups_per_matrix(emme, n, nwg):
     """The LU with 1 + S workgroups per matrix (role 0 factors A, the others carry B's columns,
     all share the back substitution; from 4 workgroups on with look-ahead: one or two of them
     carry A's trailing columns): bit-identical to the one-workgroup launch, incl. ragged
@@ -288,9 +288,9 @@ def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
     B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
     A[3, :, n // 2] = 0.0  # matrix 3 is exactly singular at column n/2 + 1
     with _ctx(emme, example_tokamak(npoints=16)) as ctx:
-        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        ctx.set_options(lu_split=1)
         tr1, info1 = ctx.trace_solve(A, B)
-        monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
+        ctx.set_options(lu_split=nwg)
         trs, infos = ctx.trace_solve(A, B)
     assert info1[3] == n // 2 + 1 and np.array_equal(info1, infos)
     assert np.isnan(trs[3].real) and np.isnan(tr1[3].real)
@@ -306,7 +306,7 @@ def test_trace_solve_several_workgroups_per_matrix(emme, monkeypatch, n, nwg):
 
 
 @pytest.mark.parametrize("n,nwg", [(512, 2), (400, 2), (448, 3), (130, 2), (70, 2), (64, 2), (37, 3), (520, 2)])
-def test_trace_solve_grouped_trailing_updates_give_the_same_bits(emme, monkeypatch, n, nwg):
+def test_trace_solve_grouped_trailing_updates_give_the_same_bits(emme, n, nwg):
     """The delayed trailing update (four panels per pass over the trailing matrix, 2-3 workgroups per
     matrix without look-ahead; default from n = 384, forced here for every n): bit-identical to the
     one-workgroup launch -- full and ragged groups, a group that is the whole matrix, a singular
@@ -318,12 +318,12 @@ def test_trace_solve_grouped_trailing_updates_give_the_same_bits(emme, monkeypat
     B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
     A[2, :, (2 * n) // 3] = 0.0  # matrix 2 is exactly singular
     with _ctx(emme, example_tokamak(npoints=16)) as ctx:
-        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        ctx.set_options(lu_split=1)
         tr1, info1 = ctx.trace_solve(A, B)
-        monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
-        monkeypatch.setenv("EMME_LU_GROUP", "16")
+        ctx.set_options(lu_split=nwg)
+        ctx.set_options(lu_group_min_n=16)
         trg, infog = ctx.trace_solve(A, B)
-        monkeypatch.setenv("EMME_LU_GROUP", "0")
+        ctx.set_options(lu_group_min_n=-1)
         tr0, info0 = ctx.trace_solve(A, B)
     assert info1[2] == (2 * n) // 3 + 1 and np.array_equal(info1, infog) and np.array_equal(info1, info0)
     ok = np.arange(nb) != 2
@@ -335,7 +335,7 @@ def test_trace_solve_grouped_trailing_updates_give_the_same_bits(emme, monkeypat
         assert abs(trg[b] - want) <= 1e-10 * max(1.0, abs(want)), (n, b, trg[b], want)
 
 
-def test_trace_solve_chunked_panel_is_independent_of_workgroups(emme, monkeypatch):
+def test_trace_solve_chunked_panel_is_independent_of_workgroups(emme):
     """n = 1024 (L21 panel in chunks of 512 rows): 2, 4, 8 and 16 workgroups per matrix give the
     same bits (with / without look-ahead, one to five A-helpers)."""
     rng = np.random.default_rng(99)
@@ -345,7 +345,7 @@ def test_trace_solve_chunked_panel_is_independent_of_workgroups(emme, monkeypatc
     res = []
     with _ctx(emme, example_tokamak(npoints=16)) as ctx:
         for nwg in ("2", "4", "8", "16"):
-            monkeypatch.setenv("EMME_LU_SPLIT", nwg)
+            ctx.set_options(lu_split=int(nwg))
             res.append(ctx.trace_solve(A, B))
     for tr, info in res:
         assert (info == 0).all()
@@ -354,7 +354,7 @@ def test_trace_solve_chunked_panel_is_independent_of_workgroups(emme, monkeypatc
     assert abs(res[0][0][0] - want) <= 1e-10 * abs(want)
 
 
-def test_trace_solve_split_falls_back_when_the_grid_cannot_be_resident(emme, monkeypatch):
+def test_trace_solve_split_falls_back_when_the_grid_cannot_be_resident(emme):
     """More workgroups than the device holds at once would wait for each other forever: the
     launcher must notice and use one workgroup per matrix (same bits, no time-out codes)."""
     rng = np.random.default_rng(5)
@@ -362,15 +362,15 @@ def test_trace_solve_split_falls_back_when_the_grid_cannot_be_resident(emme, mon
     A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n)) + 3.0 * np.eye(n)
     B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
     with _ctx(emme, example_tokamak(npoints=16)) as ctx:
-        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        ctx.set_options(lu_split=1)
         tr1, info1 = ctx.trace_solve(A, B)
-        monkeypatch.setenv("EMME_LU_SPLIT", "4")
+        ctx.set_options(lu_split=4)
         tr4, info4 = ctx.trace_solve(A, B)
     assert (info1 == 0).all() and (info4 == 0).all()
     assert np.array_equal(tr1.view(np.float64), tr4.view(np.float64))
 
 
-def test_lu_hand_over_time_out_is_bounded_and_repaired(emme, monkeypatch):
+def test_lu_hand_over_time_out_is_bounded_and_repaired(emme):
     """A helper workgroup that gives up waiting (here: after ONE poll) retires its matrix with
     EMME_EDEVICE instead of hanging; a direct call reports that per item, a root search repeats
     itself with one workgroup per matrix and returns the same bits as if it had never split."""
@@ -383,11 +383,11 @@ def test_lu_hand_over_time_out_is_bounded_and_repaired(emme, monkeypatch):
     with _ctx(emme, d) as ctx:
         for _ in range(3):  # node cache built and settled
             ctx.solve_roots(guesses)
-        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        ctx.set_options(lu_split=1)
         tr1, info1 = ctx.trace_solve(A, B)
         r1, it1, i1 = ctx.solve_roots(guesses)
-        monkeypatch.setenv("EMME_LU_SPLIT", "3")
-        monkeypatch.setenv("EMME_LU_SPIN_LIMIT", "1")
+        ctx.set_options(lu_split=3)
+        ctx.set_options(lu_spin_limit=1)
         tr3, info3 = ctx.trace_solve(A, B)
         assert set(np.unique(info3)) <= {0, -3}  # EMME_EDEVICE
         ok = info3 == 0
@@ -399,7 +399,7 @@ def test_lu_hand_over_time_out_is_bounded_and_repaired(emme, monkeypatch):
 
 
 @pytest.mark.parametrize("nwg", [2, 3])
-def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
+def test_root_search_is_independent_of_lu_workgroups(emme, nwg):
     """Whole Newton searches with 1 and with several LU workgroups per matrix: same iterates,
     same roots, bit for bit (chains retire at different steps, so the launches see dense lists
     of live matrices of changing length)."""
@@ -408,9 +408,9 @@ def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
     with _ctx(emme, d) as ctx:
         for _ in range(3):  # builds the node cache and lets it settle: later fills are identical
             ctx.solve_roots(guesses)
-        monkeypatch.setenv("EMME_LU_SPLIT", "1")
+        ctx.set_options(lu_split=1)
         r1, it1, info1, its1 = ctx.solve_roots(guesses, want_iterates=True)
-        monkeypatch.setenv("EMME_LU_SPLIT", str(nwg))
+        ctx.set_options(lu_split=nwg)
         r2, it2, info2, its2 = ctx.solve_roots(guesses, want_iterates=True)
     assert np.array_equal(it1, it2) and np.array_equal(info1, info2)
     assert np.array_equal(its1.view(np.float64), its2.view(np.float64), equal_nan=True)
@@ -418,48 +418,52 @@ def test_root_search_is_independent_of_lu_workgroups(emme, monkeypatch, nwg):
     assert len(set(it1.tolist())) > 1  # the chains did retire at different steps
 
 
-# ---- every fill kernel, forced through the context's environment switches ------------------
-KERNEL_MODES = {
-    # HBM node cache, folded records + phase table; electrostatic GK15: union-walk kernel, EM / GK31:
-    # independent lanes (the defaults); uncached integrals via the work list
-    "cached": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1"},
-    # electrostatic GK15 cases ("cached" takes the dense matrix-core fill on the tiled layout for them):
-    # every round on the vector path, every round on the matrix cores, one omega per chunk, and the
-    # union-walk kernel on the per-pair layout instead
-    "cached-dense-all-sparse": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE_MIN_COLS": "17"},
-    "cached-dense-all-mfma": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE_MIN_COLS": "1"},
-    "cached-dense-narrow": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE_MIN_TASKS": "100000000"},
-    "cached-dense-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_CACHE_MIN_DEPTH": "0"},
-    "cached-union": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_DENSE": "0"},
-    "cached-union-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_DENSE": "0", "EMME_CACHE_MIN_DEPTH": "0"},
-    # the same with the independent-lane kernel for every case
-    "cached-independent": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_UNION": "0"},
-    # unfolded records, exp(A0 + T omega) evaluated per (pair, node, omega) in the fill
-    "cached-unfolded": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_PHASE_TABLE": "0"},
-    # electromagnetic cases with one record per moment instead of the shared layout
-    "cached-em-per-moment": {"EMME_NODE_CACHE_GB": "8", "EMME_WL_MIN": "1", "EMME_EM_SHARED": "0"},
-    # cache too small for anything but the shallowest tree: most integrals are deferred
-    "cached-tiny": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_CACHE_MIN_DEPTH": "0"},
-    "cached-tiny-independent": {"EMME_NODE_CACHE_GB": "0.002", "EMME_WL_MIN": "1", "EMME_UNION": "0",
-                                "EMME_CACHE_MIN_DEPTH": "0"},
-    # no cache: omega-lane kernel (node data shared on the fly inside a lane group)
-    "omega-lane": {"EMME_NODE_CACHE_GB": "0", "EMME_WL_MIN": "1"},
-    # no cache, lanes-are-nodes kernel only
-    "nodes": {"EMME_NODE_CACHE_GB": "0", "EMME_WL_MIN": "100000"},
-}
+# ---- every fill kernel, forced through the context's options (emme_options_t) ---------------------
+def _modes(emme):
+    U, L = emme.FILL_UNION, emme.FILL_LANES
+    return {
+        # HBM node cache, folded records + phase table; electrostatic GK15: dense fill on the tiled layout, EM /
+        # GK31: independent lanes (the defaults); uncached integrals via the work list
+        "cached": dict(node_cache_gb=8.0, wl_min=1),
+        # electrostatic GK15 cases: every round on the vector path, every round on the matrix cores, one omega
+        # per chunk, a tiny cache, and the union-walk kernel on the per-pair layout instead
+        "cached-dense-all-sparse": dict(node_cache_gb=8.0, wl_min=1, dense_min_cols=17),
+        "cached-dense-all-mfma": dict(node_cache_gb=8.0, wl_min=1, dense_min_cols=1),
+        "cached-dense-narrow": dict(node_cache_gb=8.0, wl_min=1, dense_min_tasks=100000000),
+        "cached-dense-tiny": dict(node_cache_gb=0.002, wl_min=1, cache_min_depth=1),
+        "cached-union": dict(node_cache_gb=8.0, wl_min=1, fill=U),
+        "cached-union-tiny": dict(node_cache_gb=0.002, wl_min=1, fill=U, cache_min_depth=1),
+        # the same with the independent-lane kernel for every case
+        "cached-independent": dict(node_cache_gb=8.0, wl_min=1, fill=L),
+        # unfolded records, exp(A0 + T omega) evaluated per (pair, node, omega) in the fill
+        "cached-unfolded": dict(node_cache_gb=8.0, wl_min=1, phase_table=0),
+        # electromagnetic cases with one record per moment instead of the shared layout
+        "cached-em-per-moment": dict(node_cache_gb=8.0, wl_min=1, em_shared=0),
+        # cache too small for anything but the shallowest tree: most integrals are deferred
+        "cached-tiny": dict(node_cache_gb=0.002, wl_min=1, cache_min_depth=1),
+        "cached-tiny-independent": dict(node_cache_gb=0.002, wl_min=1, fill=L, cache_min_depth=1),
+        # no cache: omega-lane kernel (node data shared on the fly inside a lane group)
+        "omega-lane": dict(node_cache_gb=0.0, wl_min=1),
+        # no cache, lanes-are-nodes kernel only
+        "nodes": dict(node_cache_gb=0.0, wl_min=100000),
+    }
+
+
+KERNEL_MODES = ["cached", "cached-dense-all-sparse", "cached-dense-all-mfma", "cached-dense-narrow", "cached-dense-tiny",
+                "cached-union", "cached-union-tiny", "cached-independent", "cached-unfolded", "cached-em-per-moment",
+                "cached-tiny", "cached-tiny-independent", "omega-lane", "nodes"]
 
 
 @pytest.mark.parametrize("mode", list(KERNEL_MODES))
-def test_every_fill_kernel_matches_oracle(emme, oracle, mode, monkeypatch):
-    for k, v in KERNEL_MODES[mode].items():
-        monkeypatch.setenv(k, v)
+def test_every_fill_kernel_matches_oracle(emme, oracle, mode):
+    opts = _modes(emme)[mode]
     cases = [
         (example_tokamak(npoints=40), [-0.8 + 0.25j, -0.6 - 0.21j, 0.5 + 0.1j, -0.142 - 1.469j, 0.153 - 0.316j]),
         (example_stellarator(npoints=10), [-1.656 + 2.49j, -0.85 - 0.32j, 0.4 - 0.2j]),
     ]
     for d, ws in cases:
         po = oracle.params(d)
-        with _ctx(emme, d) as ctx:
+        with _ctx(emme, d, **opts) as ctx:
             M, iv = ctx.assemble(ws, want_intervals=True)
             M1, iv1 = ctx.assemble(ws[1:2], want_intervals=True)
         assert np.abs(M1[0] - M[1]).max() <= 1e-13 * np.abs(M[1]).max() and iv1[0] == iv[1]
@@ -474,27 +478,26 @@ def test_every_fill_kernel_matches_oracle(emme, oracle, mode, monkeypatch):
             assert np.abs(M[k] - Mo).max() <= tol * np.abs(Mo).max(), (mode, d["conf"], w)
 
 
-def test_union_fill_bits_do_not_depend_on_intervals_per_round(emme, monkeypatch):
+def test_union_fill_bits_do_not_depend_on_intervals_per_round(emme):
     """The union-walk kernel serving one or two intervals per round (and two or three items per
     lane group): a lane needs only its own next key, so every omega's matrix and interval count
     are the same bit for bit -- also for omegas whose trees barely overlap."""
-    monkeypatch.setenv("EMME_NODE_CACHE_GB", "8")
-    monkeypatch.setenv("EMME_WL_MIN", "1")
-    monkeypatch.setenv("EMME_DENSE", "0")  # the union-walk kernel itself (the default for these inputs is the dense fill)
+    # the union-walk kernel itself (the default for these inputs is the dense fill)
+    opts = dict(node_cache_gb=8.0, wl_min=1, fill=emme.FILL_UNION)
     d = example_tokamak(npoints=48)
     rng = np.random.default_rng(3)
     ws = np.concatenate([rng.uniform(-1.2, -0.4, 20) + 1j * rng.uniform(0.05, 0.4, 20),
                          [-0.142 - 1.469j, 0.153 - 0.316j, 4.591 - 3.987j, -0.35 - 0.788j, 0.6 + 0.1j]])
-    with _ctx(emme, d) as ctx:
+    with _ctx(emme, d, **opts) as ctx:
         # builds the cache and lets it grow to its final shape (a fill that deferred integrals
         # makes the next one cache a subtree around them, at most NODE_CACHE_MAX_SUB times; an
         # integral that moves from the cooperative kernel to the cached path changes its rounding)
         ctx.cache_settle(ws)
-        monkeypatch.setenv("EMME_UNION_SEL", "1")
+        ctx.set_options(union_sel=1)
         M1, iv1 = ctx.assemble(ws, want_intervals=True)
-        monkeypatch.setenv("EMME_UNION_SEL", "2")
+        ctx.set_options(union_sel=2)
         M2, iv2 = ctx.assemble(ws, want_intervals=True)
-        monkeypatch.setenv("EMME_UNION_IPG_FEW", "3")
+        ctx.set_options(union_ipg_few=3)
         M3, iv3 = ctx.assemble(ws, want_intervals=True)
         assert ctx.fill_kernel().startswith("k_assemble_union")
     assert np.array_equal(iv1, iv2) and np.array_equal(iv1, iv3)
@@ -503,13 +506,12 @@ def test_union_fill_bits_do_not_depend_on_intervals_per_round(emme, monkeypatch)
 
 
 @pytest.mark.parametrize("mode", ["cached", "cached-independent", "cached-unfolded", "omega-lane", "nodes"])
-def test_root_search_same_in_every_kernel_mode(emme, oracle, mode, monkeypatch):
-    for k, v in KERNEL_MODES[mode].items():
-        monkeypatch.setenv(k, v)
+def test_root_search_same_in_every_kernel_mode(emme, oracle, mode):
+    opts = _modes(emme)[mode]
     d = example_tokamak(npoints=32)
     po = oracle.params(d)
     guesses = np.array([-0.8 + 0.25j, -0.7 + 0.3j, -0.9 + 0.2j, -0.5 + 0.1j, 0.6 + 0.2j])
-    with _ctx(emme, d) as ctx:
+    with _ctx(emme, d, **opts) as ctx:
         roots, iters, info = ctx.solve_roots(guesses)
     for b in (0, 3):
         r_or, its_or, _, _ = oracle.solve_root(po, complex(guesses[b]))
@@ -721,18 +723,16 @@ def test_degenerate_batches_and_bad_arguments(emme, oracle):
         assert iters[0] == 1 and abs(roots[0] - its_or[0]) <= TOL_W and abs(its[0, 0] - its_or[0]) <= TOL_W
 
 
-def test_cache_policy_and_buffer_pool(emme, oracle, monkeypatch):
+def test_cache_policy_and_buffer_pool(emme, oracle):
     """Default policy: a call with fewer than 8 omegas does not build the node cache (a single
     root of a parameter scan would pay seconds of allocation for nothing), a larger one does and
     later small calls then use it; the big buffers of a destroyed context are reused by the next."""
-    monkeypatch.setenv("EMME_CACHE_MIN_BATCH", "8")
-    monkeypatch.setenv("EMME_NODE_CACHE_GB", "4")
     d = example_tokamak(npoints=24)
     po = oracle.params(d)
     ws = np.array([-0.8 + 0.25j - 0.01j * k for k in range(9)])
     Mo, _ = oracle.assemble(po, complex(ws[0]))
     for _ in range(2):  # the second context takes its buffers from the pool
-        with _ctx(emme, d) as ctx:
+        with _ctx(emme, d, cache_min_batch=8, node_cache_gb=4.0) as ctx:
             M1 = ctx.assemble(ws[:2])
             assert "cache" not in ctx.fill_kernel() and ctx.node_cache_gib() == 0.0
             M9 = ctx.assemble(ws)

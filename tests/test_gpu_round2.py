@@ -18,8 +18,8 @@ TOL_M = 1e-10
 TOL_W = 1e-9
 
 
-def _ctx(emme, d):
-    return emme.Context(emme.params_from_dict(d))
+def _ctx(emme, d, **options):
+    return emme.Context(emme.params_from_dict(d), **options)
 
 
 # ---- a8: util::bessel_i_alter_helper on the device, alone (include/functions.h:381-408) -----------
@@ -63,20 +63,19 @@ def _cfg3():
     return bench.workload_dict(256), bench.lattice(1, 0, 128)
 
 
-def test_cfg3_headline_shape_matches_reference_chains(emme, monkeypatch):
+def test_cfg3_headline_shape_matches_reference_chains(emme):
     """bench.py's workload exactly (N=256, 128-guess lattice, default routing: node cache, union
     kernel on cost-sorted chunks, multi-workgroup LU, deferred pass), on a FRESH context, against
     tests/golden/cfg3_chains.npz = every chain computed in the build container with the reference's
     kappa sources (oracle/_ref) and LAPACK zsysv (make_golden_cfg3.py): iteration counts, every
     iterate and the root of every chain the reference converges, and a second search on the now
     warm context giving the same answers."""
-    monkeypatch.delenv("EMME_CACHE_MIN_BATCH", raising=False)
     z = np.load(os.path.join(G, "cfg3_chains.npz"))
     done = z["done"].astype(bool)
     assert done.sum() >= 8
     d, g = _cfg3()
     assert np.array_equal(g, z["guesses"])
-    with _ctx(emme, d) as ctx:
+    with _ctx(emme, d, cache_min_batch=8) as ctx:  # (the library's own default, not the tests')
         roots, iters, info, its = ctx.solve_roots(g, want_iterates=True)
         assert ctx.fill_kernel().startswith("k_assemble_union") or ctx.fill_kernel().startswith("k_assemble_dense")
         roots2, iters2, info2 = ctx.solve_roots(g)
@@ -156,18 +155,17 @@ def test_rccl_gather_through_c_abi_single_rank(emme):
     comm.close()
 
 
-def test_cache_settle_is_the_canonical_state(emme, oracle, monkeypatch):
+def test_cache_settle_is_the_canonical_state(emme, oracle):
     """emme_ctx_cache_settle grows the node cache to its final shape for a set of omegas; from then
     on fills are bit-for-bit repeatable, and a second context settled the same way gives the same
     bits (fresh-vs-warm differences exist only while the cache is still growing)."""
-    monkeypatch.setenv("EMME_NODE_CACHE_GB", "8")
     d = example_tokamak(npoints=48)
     ws = np.array([-0.8 + 0.25j, -0.6 - 0.21j, -0.142 - 1.469j, 0.153 - 0.316j, 4.591 - 3.987j,
                    -0.35 - 0.788j, 0.6 + 0.1j, -0.7 + 0.3j, -0.9 + 0.1j])
     po = oracle.params(d)
     mats = []
     for _ in range(2):
-        with _ctx(emme, d) as ctx:
+        with _ctx(emme, d, node_cache_gb=8.0) as ctx:
             depth0, sub0, gib0 = ctx.cache_state()
             assert depth0 == -1 and gib0 == 0.0
             fills = ctx.cache_settle(ws)

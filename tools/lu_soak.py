@@ -21,10 +21,10 @@ for n, nb, splits in [(256, 128, ["2"]), (256, 64, ["4", "3"]), (256, 20, ["4", 
         A = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
         A = A + np.transpose(A, (0, 2, 1)) + 0.5 * n ** 0.5 * np.eye(n)
         B = rng.normal(size=(nb, n, n)) + 1j * rng.normal(size=(nb, n, n))
-        os.environ["EMME_LU_SPLIT"] = "1"
+        ctx.set_options(lu_split=1)
         tr1, i1 = ctx.trace_solve(A, B)
         for sp in splits:
-            os.environ["EMME_LU_SPLIT"] = sp
+            ctx.set_options(lu_split=int(sp))
             trs, i_s = ctx.trace_solve(A, B)
             total += 1
             if not (np.array_equal(i1, i_s) and np.array_equal(tr1.view(np.float64), trs.view(np.float64))):

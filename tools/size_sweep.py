@@ -12,13 +12,10 @@ for n in sizes:
     nb = 128 if n <= 256 else (32 if n <= 512 else 16)
     g = bench.lattice(1, 0)[:: 128 // nb][:nb]
     for cache in ("default", "0"):
-        if cache == "0":
-            os.environ["EMME_NODE_CACHE_GB"] = "0"
-        else:
-            os.environ.pop("EMME_NODE_CACHE_GB", None)
+        opts = {"node_cache_gb": 0.0} if cache == "0" else {}
         emme_amd.release_pooled_memory()
         t0 = time.perf_counter()
-        with emme_amd.Context(emme_amd.params_from_dict(bench.workload_dict(n))) as ctx:
+        with emme_amd.Context(emme_amd.params_from_dict(bench.workload_dict(n)), **opts) as ctx:
             r, it, inf = ctx.solve_roots(g)
             t1 = time.perf_counter()
             r, it, inf = ctx.solve_roots(g)
