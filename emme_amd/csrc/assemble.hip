@@ -52,6 +52,7 @@ struct AsmArgs {
     int tiled;   // the cache is in the tiled layout of the dense fill (node_cache.hpp): `recs` point to doubles
     unsigned int count_lo, count_hi;  // k_assemble_coop: run only if count_lo <= list length < count_hi
     int skip_lost;  // LIST mode: integrals of a matrix whose status flag is already set are skipped
+    const unsigned char* tile_poison[2];  // tiled cache: tiles that hold a poisoned (pair, interval) block, per class
 };
 
 // Value of the integrand at one quadrature node when a node-record cache may hold the
@@ -65,9 +66,10 @@ struct ClassTables {
     const NodeRec* recs;
     const double2* ttab;
     const double2* wtab;
+    const unsigned char* tile_poison;
 };
 __device__ __forceinline__ ClassTables class_tables(const AsmArgs& A, int cls) {
-    return ClassTables{A.recs[cls], A.ttab[cls], A.wtab[cls]};
+    return ClassTables{A.recs[cls], A.ttab[cls], A.wtab[cls], A.tile_poison[cls]};
 }
 template <int GW>
 __device__ __forceinline__ cd node_value(const AsmArgs& A, const ClassTables& ct, int depth, unsigned long long path,
@@ -90,6 +92,14 @@ __device__ __forceinline__ cd node_value(const AsmArgs& A, const ClassTables& ct
         const int sn = slotnode_of_lane(lane_in_group);
         const double4 ra = *reinterpret_cast<const double4*>(reinterpret_cast<const double2*>(blk) + tile_index(2 * sn, p));
         const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);  // (Q1, Q0) of the node: one 32-byte piece
+        // a POISONED block (k_node_cache_tiled: the folded amplitude of one of its nodes is not representable;
+        // flag in the padding slot, which the group's lane 15 has just read): this interval is evaluated unfolded,
+        // from scratch, exactly like an uncached one -- exp(A0 + T omega) with the reference's clamp and, where
+        // the reference overflows, its infinity
+        if (ct.tile_poison && ct.tile_poison[tile] != 0) {  // (uniform per integral; almost never)
+            const double flag = __shfl(ra.x, (threadIdx.x & 63 & ~(GW - 1)) | 15);
+            if (flag != 0.0) return node_eval(node_data(x, A.P, pc, oc.omi, m), oc.omega, tc);
+        }
         const double2 tt = ct.ttab[(long)cslot * GW + lane_in_group];
         const cd arg = mk(tt.x, tt.y) * oc.omega;
         // (no safe_exp clamp on tiled records, like the dense fill that shares them: node_cache.hpp;
@@ -550,6 +560,7 @@ hipError_t launch_assemble(const AssembleLaunch& L, hipStream_t stream, const No
                            const void* const ttab[2], const void* const wtab[2]) {
     AsmArgs A;
     A.tiled = 0;
+    A.tile_poison[0] = A.tile_poison[1] = nullptr;
     A.P = L.P;
     A.tab = L.tab;
     A.pairs = (const ushort2*)L.pairs;
@@ -601,8 +612,10 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                 const void* const ttab[2], const void* const wtab[2], bool folded,
-                                hipStream_t stream, bool tiled) {
+                                hipStream_t stream, bool tiled, const unsigned char* const tile_poison[2]) {
     AsmArgs A;
+    A.tile_poison[0] = (tiled && tile_poison) ? tile_poison[0] : nullptr;
+    A.tile_poison[1] = (tiled && tile_poison) ? tile_poison[1] : nullptr;
     A.tiled = tiled ? 1 : 0;
     A.P = L.P;
     A.tab = L.tab;

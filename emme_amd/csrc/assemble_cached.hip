@@ -101,7 +101,10 @@ __global__ __launch_bounds__(256) void k_node_cache(CacheArgs A) {
             // exp(T omega), which does not depend on the pair and comes from the phase table
             double sa, ca;
             sincos(d.A0.y, &sa, &ca);
-            const double ea = exp(fmin(d.A0.x, 700.0));
+            // (no cap on Re A0: where exp(A0) or exp(A0) Q is not representable -- a near-pole of 1/lambda -- the
+            // amplitudes are stored non-finite; a node the reference's clamp zeroes stays zero (the fills select),
+            // any other use ends in a non-finite integral and flags the matrix instead of a silently wrong value)
+            const double ea = exp(d.A0.x);
             const cd ex = mk(ea * ca, ea * sa);
             const cd q1 = ex * d.Q1, q0 = ex * d.Q0;
             rec.A0 = make_double2(exp(fmin(2.0 * d.A0.x, 700.0)), d.A0.x);  // (|exp A0|^2, Re A0)
@@ -148,11 +151,15 @@ __global__ __launch_bounds__(256) void k_phase_table(PhaseArgs A) {
         if (A.ttab[cls]) {
             const double2 t = A.ttab[cls][row];
             const double ax = fma(t.x, om.x, -(t.y * om.y)), ay = fma(t.x, om.y, t.y * om.x);
-            if (!(ax > 700.0)) {  // beyond: not representable (and never met where the integrand lives);
-                double sa, ca;    // a NaN omega goes through and poisons the integral, which flags it
+            if (!(ax > 700.0)) {  // (a NaN omega goes through and poisons the integral, which flags it)
+                double sa, ca;
                 sincos(ay, &sa, &ca);
                 const double ea = exp(ax);
                 ev = make_double2(ea * ca, ea * sa);
+            } else {
+                // beyond 1e304 the reference's exp(A0 + T omega) overflows or is about to: NaN, so that an integral
+                // which uses this node flags its matrix (EMME_ENUMERIC) instead of dropping the term
+                ev = make_double2(__builtin_nan(""), __builtin_nan(""));
             }
         }
         A.etab[e] = ev;

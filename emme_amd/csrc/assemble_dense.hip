@@ -63,6 +63,7 @@ struct TiledCacheArgs {
     double2* ttab;   // [NI][16]  T per (interval, node lane)
     double* scale;   // [NI]
     int part, first, count;
+    unsigned char* tile_poison;  // [ntiles] of this contour class: 1 if any (pair, interval) block of the tile is poisoned
 };
 
 // One 16-lane group per (pair, interval), lane = node (gk_lane<15>): computes the folded record and
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
         const long item = tile * TILE_PAIRS + p;
         double* blk = A.recs + ti * TILE_BLOCK;
         cd q1 = mk(0.0, 0.0), q0 = mk(0.0, 0.0);
+        bool over = false;
         int depth;
         unsigned long long path;
         A.geom.interval(A.part, idx, depth, path);
@@ -104,12 +106,16 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
             if (item < A.npairs && lane < 15) {
                 double sa, ca;
                 sincos(d.A0.y, &sa, &ca);
-                const double ea = exp(fmin(d.A0.x, 700.0));
+                const double ea = exp(d.A0.x);
                 const cd ex = mk(ea * ca, ea * sa);
                 q1 = ex * d.Q1, q0 = ex * d.Q0;
                 if (!(isfinite(q1.x) && isfinite(q1.y) && isfinite(q0.x) && isfinite(q0.y))) {
-                    // exp(A0) = 0 against an overflowing amplitude: the reference's clamp makes this
-                    // node contribute exactly 0 for every omega the integrand is finite for
+                    // Re A0 << 0: exp(A0) = 0 against an overflowing amplitude -- the reference's clamp
+                    // (Re(A0 + T omega) < -40, src/Parameters.cpp:167-173) makes this node contribute exactly 0 for
+                    // every omega the integrand is finite for.  Otherwise the folded amplitude itself is not
+                    // representable (a near-pole of 1/lambda: Re A0 > 709, or exp(A0) Q overflows): the block
+                    // is POISONED below -- whoever needs this (pair, interval) evaluates it unfolded, from scratch.
+                    over = d.A0.x > -700.0;
                     q1 = mk(0.0, 0.0), q0 = mk(0.0, 0.0);
                 }
             }
@@ -117,6 +123,13 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
                 A.ttab[(long)(A.first + idx) * GW + lane] = make_double2(d.T.x, d.T.y);
                 if (lane == 0) A.scale[A.first + idx] = scale;
             }
+        }
+        // poisoned (pair, interval): all of its records are zeroed (the GEMMs of the tile's other pairs stay finite)
+        // and the padding slot [sn = 15][p][0] carries the flag -- it multiplies a zero row of the phase block
+        const bool poisoned = ((__ballot(over) >> (threadIdx.x & 48)) & 0xffffull) != 0ull;
+        if (poisoned) {
+            q1 = mk(lane == 15 ? 1.0 : 0.0, 0.0), q0 = mk(0.0, 0.0);
+            if (lane == 15 && A.tile_poison) A.tile_poison[tile] = 1;
         }
         double2* q = reinterpret_cast<double2*>(blk);
         q[tile_index(2 * sn, p)] = make_double2(q1.x, q1.y);
@@ -148,11 +161,16 @@ __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
         if (A.ttab[cls] && lane < 15) {
             const double2 t = A.ttab[cls][(long)slot * 16 + lane];
             const double ax = fma(t.x, om.x, -(t.y * om.y)), ay = fma(t.x, om.y, t.y * om.x);
-            if (!(ax > 700.0)) {  // beyond: not representable (never met where the integrand lives);
-                double sa, ca;    // a NaN omega goes through and poisons its own column only
+            if (!(ax > 700.0)) {  // (a NaN omega goes through and poisons its own column only)
+                double sa, ca;
                 sincos(ay, &sa, &ca);
                 const double ea = exp(ax);
                 ev = mk(ea * ca, ea * sa);
+            } else {
+                // exp(T omega) beyond 1e304: the reference's exp(A0 + T omega) overflows here or is about to
+                // (Re A0 = O(1) wherever t is large enough for this).  NaN: an integral of this omega that
+                // uses the node ends non-finite and flags its matrix (EMME_ENUMERIC) instead of dropping the term
+                ev = mk(__builtin_nan(""), __builtin_nan(""));
             }
         }
         const GkLane gk = gk_lane<15>(lane);
@@ -196,6 +214,7 @@ struct DenseArgs {
     unsigned long long* intervals;
     int* status;
     unsigned long long* stats;  // [0] dense rounds, [1] sparse rounds, [2] sparse columns, [3] tile tasks
+    const unsigned char* tile_poison[2];  // per contour class: tiles that hold a poisoned (pair, interval) block
     int dense_min_cols;         // columns that must need an interval for the MFMA path
     int skip_lost;              // columns whose matrix is already flagged (status) are left alone
 };
@@ -335,6 +354,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     }
     unsigned int n_dense = 0, n_sparse = 0, n_cols = 0;
     int bad = 0;
+    // Poisoned blocks (k_node_cache_tiled: a folded amplitude that is not representable) are rare -- a handful of
+    // pairs with a near-pole of 1/lambda -- and a tile without any pays nothing for them: one flag per task.
+    const bool tile_has_poison = (A.tile_poison[0] && A.tile_poison[0][tile] != 0) || (A.tile_poison[1] && A.tile_poison[1][tile] != 0);
 #ifdef EMME_DENSE_STAMPS  // diagnostic build: where an entry spends its cycles (never in the product build)
     unsigned long long cyc_sel = 0, cyc_dense = 0, cyc_sparse = 0, cyc_dec = 0;
     const unsigned long long t_task = __builtin_amdgcn_s_memtime();
@@ -433,6 +455,19 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     }
                 }
                 Kre += K2re, Kim += K2im, Gre += G2re, Gim += G2im;
+                if (tile_has_poison) {  // (uniform) the padding row of the block: lanes 32..47 of k-step 7 hold [sn 15][pair][0]
+                    const unsigned int pm = (unsigned int)((__ballot((lane >> 4) == 2 && av[7].x != 0.0) >> 32) & 0xffffull);
+                    if (pm != 0u) {
+                        // these pairs' records of this interval are zeros: the integrals that need it restart, whole,
+                        // in the cooperative kernel, which evaluates poisoned blocks unfolded, from scratch
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (match[r] && ((pm >> (rho + 4 * r)) & 1u)) {
+                                defer(r, depth, ccls, path);
+                                match[r] = false;
+                            }
+                    }
+                }
             }
             // ---- every element that owns the interval decides for itself (include/functions.h:203-208,
             // 231-247); an entry somebody splits puts its two children on the next level's list
@@ -472,6 +507,27 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 // through LDS, square roots -- instead of four.)
                 ++n_sparse;
                 const int sn = col;
+                if (tile_has_poison) {  // (uniform) a poisoned pair's elements leave before anything is decided for them
+                    unsigned int pmk = 0u;
+                    if (col == 15) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (a2[tile_index(30, rho + 4 * r)].x != 0.0) pmk |= 1u << (rho + 4 * r);
+                    }
+                    const unsigned int pm = (unsigned)__builtin_amdgcn_readlane((int)pmk, 15) | (unsigned)__builtin_amdgcn_readlane((int)pmk, 31) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)pmk, 47) | (unsigned)__builtin_amdgcn_readlane((int)pmk, 63);
+                    if (pm != 0u) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (match[r] && ((pm >> (rho + 4 * r)) & 1u)) {
+                                defer(r, depth, ccls, path);
+                                match[r] = false;
+                            }
+                        colmask = 0u;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) colmask |= (unsigned int)((__ballot(match[r]) | (__ballot(match[r]) >> 16) | (__ballot(match[r]) >> 32) | (__ballot(match[r]) >> 48)) & 0xffffull);
+                    }
+                }
                 unsigned long long mb[4];  // who owns the entry, per element slot
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mb[r] = __ballot(match[r]);
@@ -665,8 +721,9 @@ size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part) {
 size_t btab_bytes(int nslots, int nchunks) { return (size_t)nslots * nchunks * BTAB_BLOCK * sizeof(double); }
 
 hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi, void* recs,
-                                   void* ttab, double* scale, hipStream_t stream) {
+                                   void* ttab, double* scale, hipStream_t stream, unsigned char* tile_poison) {
     TiledCacheArgs A;
+    A.tile_poison = tile_poison;
     A.P = L.P;
     A.tab = L.tab;
     A.pairs = (const ushort2*)L.pairs;
@@ -707,8 +764,11 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1], const double* scale,
                                  const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
                                  unsigned long long* defer_info, const int* act_idx, int n_act,
-                                 const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream) {
+                                 const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream,
+                                 const unsigned char* const tile_poison[2]) {
     DenseArgs A;
+    A.tile_poison[0] = tile_poison ? tile_poison[0] : nullptr;
+    A.tile_poison[1] = tile_poison ? tile_poison[1] : nullptr;
     A.P = L.P;
     A.pairs = (const ushort2*)L.pairs;
     A.npairs = L.npairs;

@@ -83,6 +83,7 @@ struct emme_ctx {
     void* d_recs_ext[2][NODE_CACHE_MAX_SUB - 1] = {};  // run-time subtrees per class
     void* d_ttab[2] = {nullptr, nullptr};      // T table per class
     void* d_wtab[2] = {nullptr, nullptr};      // moment-factor table per class (shared EM layout)
+    unsigned char* d_tile_poison[2] = {nullptr, nullptr};  // tiled layout: tiles that hold a poisoned block, per class
     bool em_shared = false;    // nm == 3: one record per (pair, interval, node), three moments per lane
     bool folded = true;        // records carry exp(A0); exp(T omega) comes from a per-launch phase table
     bool tiled = false;        // electrostatic GK15: tiled record layout + dense (matrix-core) fill
@@ -528,7 +529,15 @@ size_t cache_part_bytes(const emme_ctx* c, int gk_points, const NodeCacheGeom& g
 }
 hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCacheGeom& g, int part, int cls, void* recs) {
     const double omi = cls == 0 ? 1.0 : -1.0;
-    if (c->tiled) return launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream);
+    if (c->tiled) {
+        if (!c->d_tile_poison[cls]) {
+            const size_t ntiles = ((size_t)c->npairs + 15) / 16;
+            if (malloc_retry((void**)&c->d_tile_poison[cls], ntiles) != hipSuccess) return hipErrorOutOfMemory;
+            const hipError_t e = hipMemsetAsync(c->d_tile_poison[cls], 0, ntiles, c->stream);
+            if (e != hipSuccess) return e;
+        }
+        return launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream, c->d_tile_poison[cls]);
+    }
     return launch_node_cache(L, g, part, omi, recs, c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->folded, c->stream);
 }
 
@@ -852,7 +861,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                 }
                 HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
-                                              c->d_chunks, nchunks, c->d_rounds, c->stream));
+                                              c->d_chunks, nchunks, c->d_rounds, c->stream, c->d_tile_poison));
                 if (stamps) {
                     HIP_TRY(hipEventRecord(e1, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -909,7 +918,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             ScopedSpan s(c, K_DEFER);
             HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
                                          c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream,
-                                         c->tiled));
+                                         c->tiled, c->d_tile_poison));
         }
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
@@ -1083,7 +1092,7 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     for (int k = 0; k < 2; ++k) {
         // the big buffers go to the process-wide pool for the next context
         pool_free(c->d_recs[k], c->recs_bytes[k], c->device);
-        F(c->d_ttab[k]), F(c->d_wtab[k]);
+        F(c->d_ttab[k]), F(c->d_wtab[k]), F(c->d_tile_poison[k]);
         for (int e = 0; e < NODE_CACHE_MAX_SUB - 1; ++e) pool_free(c->d_recs_ext[k][e], c->recs_ext_bytes[k][e], c->device);
     }
     F(c->d_scale);

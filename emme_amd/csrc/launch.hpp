@@ -90,13 +90,15 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const void* const recs[2],
                                 const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1],
                                 const void* const ttab[2], const void* const wtab[2], bool folded,
-                                hipStream_t stream, bool tiled = false);
+                                hipStream_t stream, bool tiled = false, const unsigned char* const tile_poison[2] = nullptr);
 
 // ---- dense (matrix-core) fill of electrostatic GK15 contexts: assemble_dense.hip ------------------
 // tiled record layout: see node_cache.hpp
 size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part);
+// tile_poison [ntiles] (device, zeroed once per contour class): set to 1 for every tile that gets a poisoned block
 hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
-                                   void* recs, void* ttab, double* scale, hipStream_t stream);
+                                   void* recs, void* ttab, double* scale, hipStream_t stream,
+                                   unsigned char* tile_poison = nullptr);
 // weighted phase tables of one launch: btab_bytes(cached intervals, ceil(n_act / 16))
 size_t btab_bytes(int nslots, int nchunks);
 // wmap[position in the omega list] = chunk << 8 | column of that omega
@@ -108,7 +110,8 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1], const double* scale,
                                  const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
                                  unsigned long long* defer_info, const int* act_idx, int n_act,
-                                 const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream);
+                                 const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream,
+                                 const unsigned char* const tile_poison[2] = nullptr);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
