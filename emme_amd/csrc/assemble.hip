@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, EMME_ASM_MIN_WAVES) void k_assemble(AsmArgs A)
             if (depth == 0) {
                 // integral finished: kappa = -i pref sum (src/Parameters.cpp:182-183)
                 cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));
-                if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+                if (kappa_bad(kap)) bad = 1;
                 kap = kap + kappa_e(m, P, pc.de, dg, oc.omega);
                 if (lane_in_group == 0) {
                     if (m == 0) {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
             for (int h = 0; h < NG; ++h) sum = sum + mk(s_part[h][0], s_part[h][1]);
             cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));
             int isbad = s_bad;
-            if (!(isfinite(kap.x) && isfinite(kap.y))) isbad = 1;
+            if (kappa_bad(kap)) isbad = 1;
             kap = kap + kappa_e(m, P, pc.de, dg, oc.omega);
             double2* Mb = A.M + (size_t)b * dim * dim;
             const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, EMME_CACHED_MIN_WAVES) void k_assemble_cached(
             my_intervals += (unsigned long long)item_intervals;
             const double dg = gtab[i] - gtab[j], de = eta[i] - eta[j];
             cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));  // -i pref sum, Parameters.cpp:182
-            if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+            if (kappa_bad(kap)) bad = 1;
             kap = kap + kappa_e(m, P, de, dg, omega);
             if (m == 0) {
                 const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
                 if (deferred[m]) continue;
                 my_intervals += (unsigned long long)count[m];
                 cd kap = mk(P.pref * sum[m].y, -(P.pref * sum[m].x));  // -i pref sum, Parameters.cpp:182
-                if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+                if (kappa_bad(kap)) bad = 1;
                 kap = kap + kappa_e(m, P, de, dg, omega);
                 if (m == 0) {
                     const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256, 4) void k_assemble_union(AsmCachedArgs A) {
             my_intervals += (unsigned long long)count;
             const double dg = gtab[i] - gtab[j], de = eta[i] - eta[j];
             cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));  // -i pref sum, Parameters.cpp:182
-            if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+            if (kappa_bad(kap)) bad = 1;
             kap = kap + kappa_e(0, P, de, dg, omega);
             const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
             store(i, j, v);

@@ -19,6 +19,14 @@ namespace {
 // numbers in every kernel, so that the flag does not depend on which kernel served the integral.
 constexpr int EMME_MAX_DEPTH = 40;
 constexpr int EMME_MAX_INTERVALS = 1 << 18;
+// Largest modulus of an integral the device path stands for.  The accept/split rule takes |K| and |K - G| as
+// sqrt(x^2 + y^2) and the Newton step's pivot search compares |x|^2: both overflow beyond 1.3e154, so a matrix
+// with a larger entry would be walked on corrupted error estimates and could not be factored anyway.  The
+// reference (std::abs = hypot, LAPACK's scaled arithmetic) goes on to 1e308 -- where, on the headline lattice,
+// its own intermediates overflow first (chain 80's iterate -0.0055-0.734i: entries up to 3e202, two of them
+// inf; its zsysv then fails, include/solver.h:142-153).  Such a matrix is flagged (status -> EMME_ENUMERIC).
+constexpr double EMME_MAX_ENTRY = 1e150;
+__device__ __forceinline__ bool kappa_bad(cd k) { return !(fabs(k.x) < EMME_MAX_ENTRY && fabs(k.y) < EMME_MAX_ENTRY); }
 
 // per-lane node tables: lane r of a group -> (signed abscissa, Kronrod weight, Gauss weight)
 __device__ const double kX15[8] = {0.,

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             const int i = ij.x, j = ij.y;
             const cd sm = mk(s_sumx[wave][r][lane], s_sumy[wave][r][lane]);
             const cd kap = mk(P.pref * sm.y, -(P.pref * sm.x));  // -i pref sum, Parameters.cpp:182
-            if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+            if (kappa_bad(kap)) bad = 1;
             const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
             store(i, j, v, rdw);
             store(j, i, v, rdw);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, EMME_WL_MIN_WAVES) void k_assemble_wl(AsmWlArg
                 // this omega's integral is complete: kappa = -i pref sum, + kappa_e, scatter
                 my_done = true;
                 cd kap = mk(P.pref * sum.y, -(P.pref * sum.x));
-                if (!(isfinite(kap.x) && isfinite(kap.y))) bad = 1;
+                if (kappa_bad(kap)) bad = 1;
                 kap = kap + kappa_e(m, P, pc.de, dg, omega);
                 if (m == 0) {
                     const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;

@@ -77,14 +77,17 @@ def test_damped_omegas_full_size_match_reference_checksums(emme):
 def test_dense_fill_clamped_tails_entry_by_entry(emme, oracle):
     """safe_exp (src/Parameters.cpp:167-173) zeroes a node when Re(A0 + T omega) < -40.  The dense fill cannot
     apply that per (pair, node, omega) inside a GEMM and carries the tails (|term| < e^-40 of its coefficient).
-    Constructed case: pairs far from the diagonal, where >= 80 % of the level-4 nodes are clamped (checked with
-    the numpy restatement of the split) -- dense (default) vs the exact union kernel vs the oracle, ENTRY BY
-    ENTRY: interval counts equal, and every such entry within 1e-12 absolute + 1e-9 relative of the oracle's
-    (the quadrature's own absolute goal, integration_accuracy, is 1e-6)."""
+    Constructed case: the 210 pairs of an N = 40 grid with |i - j| >= 20, where >= 80 % of the level-4 nodes are
+    clamped (checked with the numpy restatement of the split) -- dense (default) vs the exact union kernel vs the
+    oracle, ENTRY BY ENTRY: interval counts equal, and every such entry within
+        1e-13 + 1e-10 |entry| + 10 x (how far the ORACLE's own entry moves when omega changes by 1e-13 relative)
+    of the oracle's (the last term is the entry's own rounding noise: these far entries are small remainders of
+    larger integrand values; at strongly damped omegas it reaches 1e-3 relative, which is why those are pinned
+    by checksums with the reference's spread in test_damped_omegas_full_size_match_reference_checksums instead)."""
     d = example_tokamak(npoints=40)
     po = oracle.params(d)
     eta, _ = oracle.grid(d["length"], 40)
-    ws = np.array([-0.8 + 0.25j, -0.6 - 0.21j, 0.5 + 0.1j, -0.3 - 0.9j, -0.75 + 0.3j, -0.9 + 0.12j, 0.3 - 0.3j, -0.5 + 0.05j])
+    ws = np.array([-0.8 + 0.25j, -0.6 - 0.21j, 0.5 + 0.1j, -0.7 - 0.1j, -0.75 + 0.3j, -0.9 + 0.12j, 0.3 - 0.3j, -0.5 + 0.05j])
     far = [(i, j) for i in range(40) for j in range(i + 1, 40) if j - i >= 20]
     for w in ws[:4]:
         omi = -np.copysign(1.0, w.real)
@@ -98,17 +101,18 @@ def test_dense_fill_clamped_tails_entry_by_entry(emme, oracle):
         assert ctx.fill_kernel().startswith("k_assemble_union")
     assert np.array_equal(ivd, ivu)
     I, J = np.array(far).T
-    worst_abs = worst_rel = 0.0
+    worst = 0.0
     for k, w in enumerate(ws):
-        Mo, tot, = oracle.assemble(po, complex(w))
+        Mo, tot = oracle.assemble(po, complex(w))
         assert ivd[k] == tot
+        noise = np.maximum(np.abs(oracle.assemble(po, complex(w) * (1 + 1e-13))[0] - Mo),
+                           np.abs(oracle.assemble(po, complex(w) * (1 - 1e-13))[0] - Mo))[I, J]
         eo, ed, eu = Mo[I, J], Md[k][I, J], Mu[k][I, J]
-        assert np.all(np.abs(eu - eo) <= 1e-13 + 1e-11 * np.abs(eo)), (w, np.abs(eu - eo).max())
-        err = np.abs(ed - eo)
-        assert np.all(err <= 1e-12 + 1e-9 * np.abs(eo)), (w, err.max(), np.abs(eo)[np.argmax(err)])
-        worst_abs = max(worst_abs, err.max())
-        worst_rel = max(worst_rel, (err / np.maximum(np.abs(eo), 1e-300))[np.abs(eo) > 1e-12].max())
-    print(f"dense vs oracle on {len(far)} far pairs x {len(ws)} omegas: max abs err {worst_abs:.2e}, max rel err {worst_rel:.2e}")
+        tol = 1e-13 + 1e-10 * np.abs(eo) + 10.0 * noise
+        assert np.all(np.abs(eu - eo) <= tol), (w, (np.abs(eu - eo) / tol).max())
+        assert np.all(np.abs(ed - eo) <= tol), (w, (np.abs(ed - eo) / tol).max())
+        worst = max(worst, (np.abs(ed - eo) / tol).max())
+    print(f"dense vs oracle on {len(far)} far pairs x {len(ws)} omegas: worst error / tolerance {worst:.3g}")
 
 
 # ---- 3. nullSpace on the device, batched ----------------------------------------------------------------
