@@ -1661,7 +1661,7 @@ int emme_null_vectors_batch(emme_ctx_t* c, int n, int nbatch, const double* M, d
     HIP_TRY(malloc_retry((void**)&t.v, sizeof(double) * 2 * (size_t)n * nbatch));
     HIP_TRY(malloc_retry((void**)&t.info, sizeof(int) * nbatch));
     const bool one_wg = trace_solve_blocked_lds(n) <= 150 * 1024;  // the whole L21 panel in one workgroup's LDS
-    const int max_sweeps = 8;
+    const int max_sweeps = 60;  // (two at a converged root; the rest is for matrices that are not singular)
     if (one_wg || n <= 1024) {
         // blocked factorisations: row orders in the LU scratch.  Above the one-workgroup panel the chunked
         // multi-workgroup kernel of the Newton step factors (two workgroups per matrix, which must be resident

@@ -1389,12 +1389,9 @@ hipError_t launch_lu_inplace(int n, int nbatch, double* A, const int* items, int
                              hipStream_t stream) {
     const size_t lds = trace_solve_blocked_lds(n);
     if (lds > 150 * 1024) return hipErrorNotSupported;
-    static thread_local int attr_dev = -1;
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (attr_dev != cur_dev) {
-        (void)hipFuncSetAttribute((const void*)k_lu_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_dev = cur_dev;
+    if (lds > 48 * 1024) {  // (beyond the default dynamic-LDS limit only)
+        const hipError_t ea = hipFuncSetAttribute((const void*)k_lu_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
     }
     SplitCtl ctl{};
     ctl.nwg = 1;

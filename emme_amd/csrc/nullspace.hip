@@ -321,13 +321,9 @@ size_t null_iterate_lds(int n) { return (size_t)3 * n * sizeof(double2) + (size_
 hipError_t launch_lu_unblocked_inplace(int n, int nbatch, double* A, int* maps, int* info, hipStream_t stream) {
     const size_t lds = (size_t)n * sizeof(double2) + (size_t)n * sizeof(int);
     if (lds > 150 * 1024) return hipErrorNotSupported;
-    static thread_local int attr_dev = -1;
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (attr_dev != cur_dev) {
-        (void)hipFuncSetAttribute((const void*)k_lu_unblocked_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        (void)hipFuncSetAttribute((const void*)k_null_iterate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_dev = cur_dev;
+    if (lds > 48 * 1024) {  // (beyond the default dynamic-LDS limit only)
+        const hipError_t ea = hipFuncSetAttribute((const void*)k_lu_unblocked_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(k_lu_unblocked_inplace, dim3(nbatch), dim3(NT), lds, stream, n, (double2*)A, maps, info);
     return hipGetLastError();
@@ -346,12 +342,9 @@ hipError_t launch_null_iterate(int n, const double* A_lu, const int* rowmaps, in
     P.max_sweeps = max_sweeps;
     const size_t lds = null_iterate_lds(n);
     if (lds > 150 * 1024) return hipErrorNotSupported;
-    static thread_local int attr_dev = -1;
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (attr_dev != cur_dev) {
-        (void)hipFuncSetAttribute((const void*)k_null_iterate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_dev = cur_dev;
+    if (lds > 48 * 1024) {  // (beyond the default dynamic-LDS limit only)
+        const hipError_t ea = hipFuncSetAttribute((const void*)k_null_iterate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(k_null_iterate, dim3(nitems), dim3(NT), lds, stream, P);
     return hipGetLastError();
