@@ -354,9 +354,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     }
     unsigned int n_dense = 0, n_sparse = 0, n_cols = 0;
     int bad = 0;
-    // Poisoned blocks (k_node_cache_tiled: a folded amplitude that is not representable) are rare -- a handful of
-    // pairs with a near-pole of 1/lambda -- and a tile without any pays nothing for them: one flag per task.
-    const bool tile_has_poison = (A.tile_poison[0] && A.tile_poison[0][tile] != 0) || (A.tile_poison[1] && A.tile_poison[1][tile] != 0);
+
 #ifdef EMME_DENSE_STAMPS  // diagnostic build: where an entry spends its cycles (never in the product build)
     unsigned long long cyc_sel = 0, cyc_dense = 0, cyc_sparse = 0, cyc_dec = 0;
     const unsigned long long t_task = __builtin_amdgcn_s_memtime();
@@ -370,6 +368,17 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)ccls << 55) | (path & 0x7fffffffffffffull);
         deferred[r] = true, alive[r] = false, mcur[r] = 0ull, mnext[r] = 0ull;
     };
+
+    // Poisoned blocks (k_node_cache_tiled: a folded amplitude that is not representable -- a handful of pairs with a
+    // near-pole of 1/lambda; 4 of the 2 040 tiles of the bench grid, contour class Re omega > 0 only) are not looked
+    // for in the rounds: a tile that holds one hands ALL its integrals of that contour class to the cooperative
+    // kernel right here, which evaluates poisoned blocks unfolded, from scratch.  (Looking for the flag in the rounds
+    // -- the padding row of every block -- cost 7 % of the fill: 17 more vector registers, 36.1 -> 38.9 ms per search.)
+    if (has_w && A.tile_poison[cls] && A.tile_poison[cls][tile] != 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (alive[r]) defer(r, 0, cls, 0ull);
+    }
 
     for (int depth = 0; n_cur > 0; ++depth) {
         int n_next = 0;
@@ -455,19 +464,6 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     }
                 }
                 Kre += K2re, Kim += K2im, Gre += G2re, Gim += G2im;
-                if (tile_has_poison) {  // (uniform) the padding row of the block: lanes 32..47 of k-step 7 hold [sn 15][pair][0]
-                    const unsigned int pm = (unsigned int)((__ballot((lane >> 4) == 2 && av[7].x != 0.0) >> 32) & 0xffffull);
-                    if (pm != 0u) {
-                        // these pairs' records of this interval are zeros: the integrals that need it restart, whole,
-                        // in the cooperative kernel, which evaluates poisoned blocks unfolded, from scratch
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (match[r] && ((pm >> (rho + 4 * r)) & 1u)) {
-                                defer(r, depth, ccls, path);
-                                match[r] = false;
-                            }
-                    }
-                }
             }
             // ---- every element that owns the interval decides for itself (include/functions.h:203-208,
             // 231-247); an entry somebody splits puts its two children on the next level's list
@@ -507,27 +503,6 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 // through LDS, square roots -- instead of four.)
                 ++n_sparse;
                 const int sn = col;
-                if (tile_has_poison) {  // (uniform) a poisoned pair's elements leave before anything is decided for them
-                    unsigned int pmk = 0u;
-                    if (col == 15) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (a2[tile_index(30, rho + 4 * r)].x != 0.0) pmk |= 1u << (rho + 4 * r);
-                    }
-                    const unsigned int pm = (unsigned)__builtin_amdgcn_readlane((int)pmk, 15) | (unsigned)__builtin_amdgcn_readlane((int)pmk, 31) |
-                                            (unsigned)__builtin_amdgcn_readlane((int)pmk, 47) | (unsigned)__builtin_amdgcn_readlane((int)pmk, 63);
-                    if (pm != 0u) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (match[r] && ((pm >> (rho + 4 * r)) & 1u)) {
-                                defer(r, depth, ccls, path);
-                                match[r] = false;
-                            }
-                        colmask = 0u;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) colmask |= (unsigned int)((__ballot(match[r]) | (__ballot(match[r]) >> 16) | (__ballot(match[r]) >> 32) | (__ballot(match[r]) >> 48)) & 0xffffull);
-                    }
-                }
                 unsigned long long mb[4];  // who owns the entry, per element slot
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mb[r] = __ballot(match[r]);

@@ -536,7 +536,17 @@ hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCach
             const hipError_t e = hipMemsetAsync(c->d_tile_poison[cls], 0, ntiles, c->stream);
             if (e != hipSuccess) return e;
         }
-        return launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream, c->d_tile_poison[cls]);
+        hipError_t e = launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream, c->d_tile_poison[cls]);
+        if (e == hipSuccess && std::getenv("EMME_DEBUG")) {
+            const size_t ntiles = ((size_t)c->npairs + 15) / 16;
+            std::vector<unsigned char> flags(ntiles);
+            (void)hipMemcpyAsync(flags.data(), c->d_tile_poison[cls], ntiles, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            int n_poison = 0;
+            for (unsigned char f : flags) n_poison += f != 0;
+            fprintf(stderr, "[emme] node cache: class %d part %d built; tiles with a poisoned block so far: %d\n", cls, part, n_poison);
+        }
+        return e;
     }
     return launch_node_cache(L, g, part, omi, recs, c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->folded, c->stream);
 }
@@ -619,6 +629,7 @@ int find_subtree(const NodeCacheGeom& g, int depth, unsigned long long path) {
 void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned long long path, int cls) {
     NodeCacheGeom& g = c->cache_geom;
     if (c->ext_failed || !c->d_recs[cls]) return;
+    if (depth <= g.dfull) return;  // (inside the full tree: a poisoned tile's hand-over, not a missing interval)
     int k = find_subtree(g, depth, path);
     const bool fresh = k < 0;
     if (k == 0) return;  // the fixed subtree lives in the main buffer: nothing to add
