@@ -48,7 +48,10 @@ sys.path.insert(0, ROOT)
 FLOP_PER_EVAL = 900.0       # 560 plain fp64 flops + 8 transcendentals + hypots
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X fp64 vector peak = fp64 MFMA peak
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md chip table
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+MACHINE_BALANCE = FP64_VECTOR_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)  # 9.8 flop/B: left of it a kernel is memory-side limited
+PMC_SUMMARIES = {3: os.path.join(ROOT, "profiles", "r03_pmc_summary.json"),
+                 4: os.path.join(ROOT, "profiles", "r03_cfg4_pmc_summary.json"),
+                 5: os.path.join(ROOT, "profiles", "r03_cfg5_pmc_summary.json")}
 GOLDEN_CFG3 = os.path.join(ROOT, "tests", "golden", "cfg3_chains.npz")
 
 # The two shipped example inputs as data (values of the reference's input-example.json:1-37 and
@@ -116,7 +119,18 @@ def usable_cores():
     return n
 
 
-def cpu_root_searches(d, guesses, kind, budget_s):
+def kernel_source_sha16():
+    """sha256 of the device sources: the stamp a PMC summary carries (tools/pmc_summary.py) -- .git does not travel
+    to the GPU box, the sources do."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "emme_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_root_searches(d, guesses, kind, budget_s, tol=None, limit=None):
     """The reference's solve-once sequence on the host cores, chain after chain, until the budget is
     spent.  kind "reference": oracle/_ref (the reference's own kappa/quadrature sources) fills the
     matrix; kind "port": the C restatement oracle/emme_oracle.c with the reference's per-call
@@ -125,7 +139,9 @@ def cpu_root_searches(d, guesses, kind, budget_s):
     (src/main.cpp:25-76): initial, Iteration (of which integration, linear solver)."""
     from oracle.binding import Oracle, Reference
     cores = usable_cores()
-    n, tol, limit = d["npoints"], d["iteration_precision"], d["iteration_step_limit"]
+    n = d["npoints"] if d["beta_e"] == 0.0 else 2 * d["npoints"]  # include/solver.h:406-407
+    tol = d["iteration_precision"] if tol is None else tol
+    limit = d["iteration_step_limit"] if limit is None else limit
     if kind == "reference":
         ref = Reference()
         ref.open_dict(d)
@@ -172,29 +188,30 @@ def cpu_root_searches(d, guesses, kind, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": points / dt, "unit": "omega-points/s", "cores": cores, "kind": kind,
-            "sample": f"{len(chains)} of the lattice guesses (every 16th from #7), full root search each: "
-                      f"{points} omega-points in {dt:.1f} s",
+            "sample": f"{len(chains)} of this workload's guesses, the reference's solve-once sequence each "
+                      f"(tol {tol:g}, step limit {limit}): {points} omega-points in {dt:.1f} s",
             "roots_per_s": len(chains) / dt,
             "phases_s": {k: round(v, 3) for k, v in ph.items()}}, chains
 
 
-def cpu_baseline(d, guesses, gpu_roots, gpu_iters, sample_idx):
+def cpu_baseline(d, guesses, gpu_roots, gpu_iters, sample_idx, tol=None, limit=None, budget=(18.0, 8.0)):
     """cpu_baseline object of the bench line + the parity of the GPU roots against the CPU roots of
     the same guesses (the CPU leg is the checker here, never the thing measured as `value`)."""
     from oracle.binding import Reference
     out, chains = None, []
     if Reference.available():
-        out, chains = cpu_root_searches(d, guesses, "reference", 18.0)
-        port, _ = cpu_root_searches(d, guesses, "port", 8.0)
+        out, chains = cpu_root_searches(d, guesses, "reference", budget[0], tol, limit)
+        port, _ = cpu_root_searches(d, guesses, "port", budget[1], tol, limit)
         out["port"] = {k: port[k] for k in ("value", "sample", "phases_s")}
         out["note"] = ("kind=reference: oracle/_ref/libemme_ref.so, the reference's own kappa sources built in the "
                        "build container, travelled to this box as a built file; `port` = the C restatement timed "
                        "beside it (it is not a strawman: same algorithm, same per-call g()/bi() re-evaluation)")
     else:
-        out, chains = cpu_root_searches(d, guesses, "port", 25.0)
+        out, chains = cpu_root_searches(d, guesses, "port", budget[0] + budget[1], tol, limit)
     err, rel, n_cmp, it_mismatch = 0.0, 0.0, 0, 0
+    fixed_work = tol == 0.0
     for (g, w, k, ok), b in zip(chains, sample_idx):
-        if not ok:
+        if not ok and not fixed_work:
             continue  # a chain the reference itself does not converge has no root to compare
         e = abs(gpu_roots[b] - w)
         err, rel = max(err, e), max(rel, e / abs(w))
@@ -233,14 +250,47 @@ def golden_parity(roots, iters, info):
             "reference_failed_chains_fail_here_too": bool(np.all(info[failed_ref] != 0))}
 
 
-def pmc_summary(kernel):
-    """Executed-work figures of `kernel` from the committed rocprofv3 --pmc summary of this build
-    (profiles/, separate passes, see profiles/README.md); bench.py cannot collect hardware counters
-    itself.  Returns the kernel's dict or None."""
+def pmc_summary(cfg):
+    """The committed rocprofv3 --pmc summary of this configuration's workload (profiles/, separate passes per
+    counter group, tools/pmc_collect.sh + tools/pmc_summary.py; see profiles/README.md) -- bench.py cannot collect
+    hardware counters itself.  Returns (summary dict or None, path, stale): stale = the device sources have
+    changed since the counters were taken (the summary carries their sha256)."""
+    path = PMC_SUMMARIES.get(cfg)
     try:
-        return json.load(open(PMC_SUMMARY))["kernels"][kernel]
-    except (OSError, KeyError, ValueError):
-        return None
+        sm = json.load(open(path))
+    except (OSError, ValueError, TypeError):
+        return None, path, None
+    return sm, path, sm.get("source_sha16") != kernel_source_sha16()
+
+
+def executed_roofline(pm, avg_launch_s):
+    """Executed-work roofline of one kernel from its PMC sums (per launch) and a launch duration measured in THIS
+    run: FP64 operations issued / peak, corrected HBM-side traffic / peak, and which of the two binds (arithmetic
+    intensity against the machine balance of 9.8 flop/B)."""
+    flop = pm["fp64_flop_issued_per_launch"]
+    raw_rd, wr = pm.get("hbm_fetch_bytes_per_launch"), pm.get("hbm_write_bytes_per_launch")
+    # MI355X_MICROARCH.md, HBM / rocprofv3 section: on gfx950 FETCH_SIZE tallies a wide coalesced read (16 B per lane:
+    # every record / operand read of these kernels) at HALF its bytes; WRITE_SIZE is exact for 16-B stores
+    traffic = (2.0 * raw_rd + wr) if raw_rd is not None and wr is not None else None
+    ach = flop / avg_launch_s / 1e12
+    out = {"achieved": ach, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TF,
+           "fp64_flop_issued_per_launch": flop,
+           "mfma_share_of_flop": pm.get("fp64_mfma_flop_per_launch", 0.0) / flop if flop else None,
+           "lane_utilisation": pm.get("lane_utilisation"),
+           "frac_useful_lanes": ach * pm.get("lane_utilisation", 1.0) / FP64_VECTOR_PEAK_TF,
+           "mfma_busy_per_wave_cycle": pm.get("SQ_VALU_MFMA_BUSY_CYCLES_per_wave_cycle"),
+           "wait_any_per_wave_cycle": pm.get("SQ_WAIT_ANY_per_wave_cycle"),
+           "l2_hit_rate": pm.get("l2_hit_rate"),
+           "traffic": traffic, "traffic_raw_fetch": raw_rd, "traffic_write": wr}
+    if traffic:
+        gbs = traffic / avg_launch_s / 1e9
+        ai = flop / traffic
+        out.update({"hbm_achieved_GBps": gbs, "hbm_peak_GBps": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
+                    "arithmetic_intensity_flop_per_byte": ai, "machine_balance_flop_per_byte": MACHINE_BALANCE,
+                    "bound": "hbm" if ai < MACHINE_BALANCE else "mfma"})
+    else:
+        out["bound"] = "mfma" if (out["mfma_share_of_flop"] or 0.0) > 0.5 else "fp64-valu"
+    return out
 
 
 def free_port():
@@ -365,6 +415,19 @@ def main():
                         "node cache, its build kernels and cache growth included); the timed steps below run on "
                         "the prepared context"}
 
+    class ProfSum:  # configs[4]: a context per k_rho -- their profiles added up
+        FIELDS = [f[0] for f in emme_amd.Profile._fields_]
+
+        def __init__(self):
+            for f in self.FIELDS:
+                setattr(self, f, 0)
+
+        def add(self, pr):
+            for f in self.FIELDS:
+                setattr(self, f, getattr(self, f) + getattr(pr, f))
+
+    prof5 = {"sum": ProfSum(), "on": False, "dim": None, "kernel": None, "gib": 0.0}
+
     def step():
         if cfg == 5:
             rs, its, infs = [], [], []
@@ -372,7 +435,12 @@ def main():
                 with emme_amd.Context(emme_amd.params_from_dict(workload_dict(npoints, k_rho=float(kr))),
                                       device=local_rank) as c5:
                     c5.set_stream(stream.cuda_stream)
+                    if prof5["on"]:
+                        c5.profile(True)
                     r, i, f = c5.solve_roots(guesses)
+                    if prof5["on"]:
+                        prof5["sum"].add(c5.profile_read())
+                        prof5["dim"], prof5["kernel"], prof5["gib"] = c5.dim, c5.fill_kernel_symbol(), c5.node_cache_gib()
                 rs.append(r), its.append(i), infs.append(f)
             roots, iters, info = np.concatenate(rs), np.concatenate(its), np.concatenate(infs)
         else:
@@ -385,6 +453,7 @@ def main():
     if ctx is not None:
         ctx.profile(True)
         ctx.profile_read(reset=True)
+    prof5["on"] = True
     barrier()
     t0 = time.perf_counter()
     points = 0
@@ -393,7 +462,10 @@ def main():
         points += int(iters[info == 0].sum())
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read() if ctx is not None else None
+    prof = ctx.profile_read() if ctx is not None else prof5["sum"]
+    fill_symbol = ctx.fill_kernel_symbol() if ctx is not None else prof5["kernel"]
+    mat_dim = ctx.dim if ctx is not None else prof5["dim"]
+    cache_gib = ctx.node_cache_gib() if ctx is not None else prof5["gib"]
 
     stats = torch.tensor([dt, float(points), float((info == 0).sum()), float(len(roots)),
                           float(iters[info != 0].sum())], dtype=torch.float64, device="cuda")
@@ -454,53 +526,71 @@ def main():
             asm_s = prof.assemble_ms * 1e-3
             n_launch = max(prof.assemble_launches, 1)
             avg_launch_s = asm_s / n_launch
-            kname = ctx.fill_kernel_symbol()
-            pm = pmc_summary(kname)
+            kname = fill_symbol
+            sm, sm_path, stale = pmc_summary(cfg)
+            pm = (sm or {}).get("kernels", {}).get(kname)
             # algorithmic convention of SURVEY 8(d): integrand evaluations the REFERENCE algorithm performs
             # for these matrices (counted exactly by the kernels: GK intervals x nodes) x 900 flop-eq
             alg_tf = evals * FLOP_PER_EVAL / fill_s / 1e12 if fill_s > 0 else 0.0
-            # the dense fill issues most of its flop on the FP64 matrix cores (whose dense peak equals the
-            # FP64 vector peak on MI355X: 78.6 TFLOP/s); the other fill kernels are vector-only
-            roof = {"bound": "mfma" if kname == "k_assemble_dense" else "fp64-valu", "kernel": kname,
-                    "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                    "avg_launch_ms": avg_launch_s * 1e3, "launches": prof.assemble_launches,
+            dim = mat_dim
+            matrix_bytes_per_launch = prof.matrices * dim * dim * 48.0 / n_launch  # M, M' written, M_old read
+            roof = {"kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": prof.assemble_launches,
                     "algorithmic_speedup_vs_fp64_peak": alg_tf / FP64_VECTOR_PEAK_TF,
                     "algorithmic_TFLOPeq_per_s": alg_tf, "flop_per_eval_convention": FLOP_PER_EVAL,
-                    "integrand_evals_per_launch": evals / n_launch}
+                    "integrand_evals_per_launch": evals / n_launch,
+                    "algorithmic_matrix_bytes_per_launch": matrix_bytes_per_launch}
             if pm and "fp64_flop_issued_per_launch" in pm:
-                ach = pm["fp64_flop_issued_per_launch"] / avg_launch_s / 1e12
+                roof.update(executed_roofline(pm, avg_launch_s))
+                if roof.get("traffic"):
+                    roof["traffic_over_matrix_bytes"] = roof["traffic"] / matrix_bytes_per_launch
                 roof.update({
-                    "achieved": ach, "frac": ach / FP64_VECTOR_PEAK_TF,
-                    "frac_useful_lanes": ach * pm.get("lane_utilisation", 1.0) / FP64_VECTOR_PEAK_TF,
-                    "lane_utilisation": pm.get("lane_utilisation"),
-                    "fp64_share_of_valu_instructions": pm.get("fp64_share_of_valu"),
-                    "fp64_flop_issued_per_launch": pm["fp64_flop_issued_per_launch"],
-                    "mfma_share_of_flop": (pm.get("fp64_mfma_flop_per_launch", 0.0) / pm["fp64_flop_issued_per_launch"]
-                                           if pm["fp64_flop_issued_per_launch"] else None),
-                    "mfma_busy_per_wave_cycle": pm.get("SQ_VALU_MFMA_BUSY_CYCLES_per_wave_cycle"),
-                    "traffic": pm.get("hbm_fetch_bytes_per_launch", 0.0) + pm.get("hbm_write_bytes_per_launch", 0.0),
-                    "traffic_corrected": 2.0 * pm.get("hbm_fetch_bytes_per_launch", 0.0) + pm.get("hbm_write_bytes_per_launch", 0.0),
-                    "note": "EXECUTED work: FP64 operations issued by the dominant fill kernel per launch (rocprofv3 "
-                            "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2 flop, + 512 x SQ_INSTS_VALU_MFMA_MOPS_F64; "
-                            f"{os.path.relpath(PMC_SUMMARY, ROOT)}, same workload) / hipEvent launch duration measured "
-                            "in THIS run / fp64 vector peak.  frac_useful_lanes = x lane utilisation.  `traffic` = raw "
-                            "FETCH_SIZE + WRITE_SIZE per launch, traffic_corrected with the gfx950 x2 read correction. "
-                            "algorithmic_speedup_vs_fp64_peak is the SURVEY 8(d) convention (900 flop-eq per "
-                            "integrand evaluation of the REFERENCE algorithm): a speed-up over a peak-rate "
-                            "reference-style kernel, not a utilisation"})
+                    "pmc_summary": os.path.relpath(sm_path, ROOT), "pmc_source_sha16": sm.get("source_sha16"),
+                    "pmc_stale": bool(stale),
+                    "note": "EXECUTED work of the dominant fill kernel per launch from the committed rocprofv3 --pmc summary of "
+                            "this workload (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, FMA = 2 flop, + 512 x "
+                            "SQ_INSTS_VALU_MFMA_MOPS_F64; FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE) divided by the "
+                            "hipEvent launch duration measured in THIS run.  achieved / frac: FP64 operations issued against the "
+                            "78.6 TFLOP/s FP64 peak (vector = matrix on gfx950); hbm_frac: corrected HBM-side bytes against 8 TB/s; "
+                            "bound: arithmetic intensity (flop issued / corrected byte) against the machine balance of 9.8 flop/B.  "
+                            "pmc_stale = the device sources changed after the counters were taken (the numerators are then those "
+                            "of an earlier build).  algorithmic_speedup_vs_fp64_peak is the SURVEY 8(d) convention (900 flop-eq per "
+                            "integrand evaluation of the REFERENCE algorithm): a speed-up over a peak-rate reference-style "
+                            "kernel, not a utilisation"})
             else:
-                roof.update({"achieved": None, "frac": None, "traffic": None,
-                             "note": f"no PMC summary for {kname} under profiles/ (executed-work roofline unavailable)"})
+                roof.update({"bound": None, "achieved": None, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": None,
+                             "traffic": None,
+                             "note": f"no PMC summary for {kname} in {os.path.relpath(sm_path, ROOT) if sm_path else 'profiles/'} "
+                                     "(executed-work roofline unavailable)"})
             out["roofline"] = roof
-            dim = ctx.dim
-            nodes = 15 if d["integration_start_points"] == 15 else 31
+            # ---- the Newton linear step (LU + n right-hand sides + trace), all its kernels together
+            lu_k = {k: v for k, v in (sm or {}).get("kernels", {}).items() if k.startswith("k_trace_solve") and "fp64_flop_issued_per_launch" in v}
+            searches = (sm or {}).get("searches")
+            if lu_k and searches and prof.linstep_ms > 0:
+                flop = sum(v["fp64_flop_issued_per_launch"] * v["launches"] for v in lu_k.values()) / searches
+                rd = sum(v.get("hbm_fetch_bytes_per_launch", 0.0) * v["launches"] for v in lu_k.values()) / searches
+                wr = sum(v.get("hbm_write_bytes_per_launch", 0.0) * v["launches"] for v in lu_k.values()) / searches
+                lu_s = prof.linstep_ms * 1e-3 / args.steps
+                n_lu = dim
+                steps_per_search = total_points / args.steps / world + float(stats[4]) / world
+                out["roofline_lu"] = {
+                    "kernels": sorted(lu_k), "ms_per_step": lu_s * 1e3, "launches_per_step": prof.linstep_launches / args.steps,
+                    "achieved": flop / lu_s / 1e12, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": flop / lu_s / 1e12 / FP64_VECTOR_PEAK_TF, "fp64_flop_issued_per_step": flop,
+                    "algorithmic_flop_per_step": (32.0 / 3.0) * n_lu ** 3 * steps_per_search,
+                    "traffic": 2.0 * rd + wr, "hbm_achieved_GBps": (2.0 * rd + wr) / lu_s / 1e9, "hbm_frac": (2.0 * rd + wr) / lu_s / 1e9 / HBM_PEAK_GBS,
+                    "arithmetic_intensity_flop_per_byte": flop / (2.0 * rd + wr) if rd + wr > 0 else None,
+                    "bound": ("hbm" if rd + wr > 0 and flop / (2.0 * rd + wr) < MACHINE_BALANCE else "mfma"),
+                    "pmc_stale": bool(stale),
+                    "note": "all LU launches of a step together: FP64 operations issued (PMC, per search of the summary's workload) / "
+                            "the LU time of a step in THIS run (hipEvents); algorithmic = (32/3) n^3 per omega-point (SURVEY 8d)"}
             out["assembly_hbm"] = {
                 "matrix_bytes_written_GBps": prof.matrices * dim * dim * 32.0 / fill_s / 1e9 if fill_s > 0 else 0.0,
                 "peak": HBM_PEAK_GBS,
-                "measured_GBps": (roof.get("traffic") / avg_launch_s / 1e9) if roof.get("traffic") else None,
-                "note": "north_star's 'assembly HBM GB/s': M and M' written (32 B per entry); the fill is FP64-ALU "
-                        "bound (SURVEY 0.4), so this is << 8 TB/s by construction; measured = PMC traffic / launch time"}
-            out["node_cache_gib"] = ctx.node_cache_gib()
+                "measured_GBps": roof.get("hbm_achieved_GBps"),
+                "note": "north_star's 'assembly HBM GB/s': matrix_bytes_written = M and M' (32 B per entry) over the fill time; "
+                        "measured_GBps = HBM-side traffic of the dominant fill kernel (PMC, gfx950-corrected) over its launch time -- "
+                        "node-record and phase-table reads, not matrix bytes"}
+            out["node_cache_gib"] = cache_gib
             out["kernels_ms_per_step"] = {
                 "fill_main": prof.assemble_ms / args.steps,
                 "fill_deferred": prof.deferred_ms / args.steps,
@@ -509,21 +599,32 @@ def main():
                 "host_gaps_and_copies": dt / args.steps * 1e3 - (prof.assemble_ms + prof.deferred_ms + prof.linstep_ms
                                                                   + prof.other_ms) / args.steps,
             }
-            _ = nodes
         if cfg == 3 and world == 1 and args.per_gpu == 128 and npoints == 256:
             gp = golden_parity(roots, iters, info)
             if gp is not None:
                 out["parity_golden"] = gp
-        if not args.no_cpu_baseline and world == 1 and cfg == 3:
-            sample = list(range(7, len(guesses), 16))
-            out["cpu_baseline"], par = cpu_baseline(d, guesses[7::16], roots, iters, sample)
+        if not args.no_cpu_baseline and world == 1:
+            if cfg == 3:
+                sample = list(range(7, len(guesses), 16))
+                out["cpu_baseline"], par = cpu_baseline(d, guesses[7::16], roots, iters, sample)
+            elif cfg == 4:
+                # fixed work (K = 8 steps, no stopping test) on two of this share's guesses: dim 512, GK31, three
+                # integrals per pair -- about 10 s of host time per chain
+                sample = [0, len(guesses) // 2]
+                out["cpu_baseline"], par = cpu_baseline(d, guesses[sample], roots, iters, sample, tol=0.0, limit=7,
+                                                        budget=(10.0, 4.0))
+            else:
+                # the first k_rho of this share, two of its 32 guesses (N = 512: about 1.5 s per assembly on 16 cores)
+                sample = [5, 20]
+                out["cpu_baseline"], par = cpu_baseline(d, guesses[sample], roots, iters, sample, budget=(12.0, 5.0))
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             out["parity_sample_max_abs_err"] = par["max_abs_err"]
             out["parity_sample"] = par
         print(json.dumps(out), flush=True)
         # the bench checks itself: GPU roots must be the reference's (1e-9 relative)
         fail = []
-        if out.get("parity_sample", {}).get("chains_compared", 0) and out["parity_sample"]["max_rel_err"] > 1e-9:
+        par_tol = 1e-8 if cfg == 4 else 1e-9  # (configs[3]: loose quadrature goal 1e-2, fixed work: the K = 8 tests' bar)
+        if out.get("parity_sample", {}).get("chains_compared", 0) and out["parity_sample"]["max_rel_err"] > par_tol:
             fail.append(f"live CPU sample: max rel err {out['parity_sample']['max_rel_err']:.3e}")
         if out.get("parity_golden") and out["parity_golden"]["compared"] and out["parity_golden"]["max_rel_err"] > 1e-9:
             fail.append(f"golden chains: max rel err {out['parity_golden']['max_rel_err']:.3e}")

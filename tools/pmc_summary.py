@@ -19,6 +19,8 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
 root, out = sys.argv[1], sys.argv[2]
+searches = int(sys.argv[3]) if len(sys.argv) > 3 else 2  # root searches (bench steps) the profiled program ran
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 acc, launches = {}, {}
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     seen = set()
@@ -31,7 +33,10 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
         seen.add((k, r["Dispatch_Id"]))
     for k, _ in seen:
         launches.setdefault(k, {})[f] = launches.setdefault(k, {}).get(f, 0) + 1
-res = {"kernels": {}}
+import bench
+res = {"kernels": {}, "searches": searches, "source_sha16": bench.kernel_source_sha16(),
+       "note": "per kernel: counter sums over all launches of `searches` root searches (steps) of the workload; "
+               "source_sha16 = sha256 of emme_amd/csrc/*.h* at collection time (bench.py marks the summary stale when it differs)"}
 for k, c in acc.items():
     n = max(launches[k].values())
     d = dict(c)
