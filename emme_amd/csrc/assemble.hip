@@ -386,6 +386,12 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     const TransConsts TC = trans_consts_v();  // (vector registers: see trans_consts_v)
 #endif
     const int N = P.N, dim = P.dim;
+    // (the list length first: both variants are launched for every fill with a grid sized for the longest list, and
+    // almost always the list is short or empty -- a workgroup without an item must not stage tables: 0.125 ms per
+    // launch, 2.6 ms per bench search, went into exactly that)
+    const int nitems = (int)*A.worklist_count;
+    if ((unsigned)nitems < A.count_lo || (unsigned)nitems >= A.count_hi) return;  // the other variant's list
+    if ((int)blockIdx.x >= nitems) return;
     for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) lds_tab[k] = A.tab[k];
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
@@ -399,9 +405,6 @@ __global__ __launch_bounds__(BT) void k_assemble_coop(AsmArgs A) {
     const GkLane gk = gk_lane<PTS>(lane_in_group);
     const double qa = 0.0, qb = M_PI / 2.0;
     const double inv_scale = 2. / (qb - qa);
-    const int nitems = (int)*A.worklist_count;
-    if ((unsigned)nitems < A.count_lo || (unsigned)nitems >= A.count_hi) return;  // the other variant's list
-
     int trip = 0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++trip) {
         const unsigned long long e = A.worklist[item];
