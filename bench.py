@@ -309,6 +309,8 @@ def parse_args():
     ap.add_argument("--per-gpu", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the no-cache / cold-start side measurements")
+    ap.add_argument("--require-c-abi-gather", action="store_true",
+                    help="exit with code 4 instead of falling back to torch.distributed when emme_gather_roots cannot be used")
     return ap.parse_args()
 
 
@@ -343,12 +345,19 @@ def main():
     gather_kind = "none (1 rank)"
     sg = None
     if use_dist:
+        from emme_amd.scan import ScanGatherUnavailable
         try:
+            # (collective, with agreement over the process group: every rank gets the communicator or every rank
+            # gets ScanGatherUnavailable -- never a mixture of collectives)
             sg = ScanGather(rank, world, device=local_rank)
             gather_kind = "emme_gather_roots (C ABI, ncclAllGather / RCCL)"
-        except Exception as e:  # never lose the scaling run over the 4 KiB gather
-            print(f"warning: RCCL gather through the C ABI unavailable ({e}); using torch.distributed", file=sys.stderr)
-            gather_kind = "torch.distributed all_gather_into_tensor (RCCL)"
+        except ScanGatherUnavailable as e:
+            if args.require_c_abi_gather:
+                print(f"rank {rank}: the C-ABI RCCL gather is required but unavailable: {e}", file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(4)
+            print(f"warning: RCCL gather through the C ABI unavailable on all ranks ({e}); using torch.distributed", file=sys.stderr)
+            gather_kind = "torch.distributed all_gather_into_tensor (RCCL) -- FALL-BACK, the C-ABI communicator could not be created"
 
     def barrier():
         torch.cuda.synchronize()

@@ -7,9 +7,11 @@ if the HIP library or a gfx950 device is missing.
 from ._lib import (EmmeError, Params, Profile, Context, params_from_json, params_from_dict,
                    tables, weight, lib_path, load, json_text, null_vector, scan_values, run_json,
                    release_pooled_memory, Comm, comm_unique_id, bessel, Options, default_options,
-                   set_default_options, FILL_AUTO, FILL_UNION, FILL_LANES)
+                   set_default_options, FILL_AUTO, FILL_UNION, FILL_LANES, comm_available,
+                   gather_pack, gather_unpack)
 
 __all__ = ["EmmeError", "Params", "Profile", "Context", "params_from_json", "params_from_dict",
            "tables", "weight", "lib_path", "load", "json_text", "null_vector", "scan_values", "run_json",
            "release_pooled_memory", "Comm", "comm_unique_id", "bessel", "Options", "default_options",
-           "set_default_options", "FILL_AUTO", "FILL_UNION", "FILL_LANES"]
+           "set_default_options", "FILL_AUTO", "FILL_UNION", "FILL_LANES", "comm_available", "gather_pack",
+           "gather_unpack"]

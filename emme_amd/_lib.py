@@ -167,6 +167,11 @@ def load():
     lib.emme_comm_destroy.argtypes = [P]
     lib.emme_comm_destroy.restype = None
     lib.emme_gather_roots.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P, P, P]
+    lib.emme_comm_available.argtypes = []
+    lib.emme_gather_slots.argtypes = [C.c_int, C.c_int]
+    lib.emme_gather_share.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.emme_gather_pack.argtypes = [C.c_int, C.c_int, P, P, P, C.c_int, C.c_int, P]
+    lib.emme_gather_unpack.argtypes = [C.c_int, C.c_int, P, P, P, P]
     _LIB = lib
     return lib
 
@@ -276,6 +281,36 @@ def release_pooled_memory() -> None:
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_available() -> bool:
+    """Can RCCL be bound in this process?  Not a collective (see emme_comm_available)."""
+    return load().emme_comm_available() == 0
+
+
+def gather_pack(rank: int, world: int, roots, iters, info, n_total: int) -> np.ndarray:
+    """emme_gather_pack: this rank's 4 m doubles of the all-gather (host only)."""
+    lib = load()
+    r = np.ascontiguousarray(roots, dtype=np.complex128)
+    it = np.ascontiguousarray(iters, dtype=np.int32)
+    inf = np.ascontiguousarray(info, dtype=np.int32)
+    m = lib.emme_gather_slots(n_total, world)
+    if m < 0:
+        _check(m)
+    send = np.zeros(4 * m)
+    _check(lib.emme_gather_pack(rank, world, r.ctypes.data, it.ctypes.data, inf.ctypes.data, len(r), n_total,
+                                send.ctypes.data))
+    return send
+
+
+def gather_unpack(world: int, n_total: int, allbuf):
+    """emme_gather_unpack: the all-gather's world * 4 m doubles in item order (host only)."""
+    a = np.ascontiguousarray(allbuf, dtype=np.float64)
+    ra = np.zeros(n_total, dtype=np.complex128)
+    ia = np.zeros(n_total, dtype=np.int32)
+    fa = np.zeros(n_total, dtype=np.int32)
+    _check(load().emme_gather_unpack(world, n_total, a.ctypes.data, ra.ctypes.data, ia.ctypes.data, fa.ctypes.data))
+    return ra, ia, fa
 
 
 def comm_unique_id() -> bytes:

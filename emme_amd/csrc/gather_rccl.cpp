@@ -96,6 +96,60 @@ static_assert(EMME_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId is passe
 
 extern "C" {
 
+// ---- the slot mapping of the gather, host only (no RCCL, no device: unit-tested on the CPU build) -----------------
+// Every rank contributes m = ceil(n_total / world) slots of 4 doubles {w_re, w_im, iters, info}; its n_local results
+// fill the first slots, the rest is NaN padding.  Item k of the scan was solved by rank k mod world and sits in that
+// rank's slot k / world.
+int emme_gather_slots(int n_total, int world) {
+    if (n_total < 1 || world < 1) return EMME_EINVAL;
+    return (n_total + world - 1) / world;
+}
+
+int emme_gather_share(int n_total, int world, int rank) {
+    if (n_total < 1 || world < 1 || rank < 0 || rank >= world) return EMME_EINVAL;
+    return rank < n_total ? (n_total - rank + world - 1) / world : 0;
+}
+
+int emme_gather_pack(int rank, int world, const double* roots, const int* iters, const int* info, int n_local,
+                     int n_total, double* send) {
+    if (!send || n_local < 0 || (n_local > 0 && (!roots || !iters || !info))) return EMME_EINVAL;
+    const int share = emme_gather_share(n_total, world, rank);
+    if (share < 0) return EMME_EINVAL;
+    // the deal is fixed: checked BEFORE any collective -- a rank with a different idea of its share would enter the
+    // all-gather with the wrong contents
+    if (n_local != share) {
+        emme::set_error("emme_gather_roots: n_local does not match the round-robin share of this rank");
+        return EMME_EINVAL;
+    }
+    const size_t m = (size_t)emme_gather_slots(n_total, world);
+    for (size_t q = 0; q < 4 * m; ++q) send[q] = std::numeric_limits<double>::quiet_NaN();
+    for (int k = 0; k < n_local; ++k) {
+        send[4 * (size_t)k + 0] = roots[2 * k];
+        send[4 * (size_t)k + 1] = roots[2 * k + 1];
+        send[4 * (size_t)k + 2] = (double)iters[k];
+        send[4 * (size_t)k + 3] = (double)info[k];
+    }
+    return EMME_OK;
+}
+
+int emme_gather_unpack(int world, int n_total, const double* all, double* roots_all, int* iters_all, int* info_all) {
+    if (!all || !roots_all || !iters_all || !info_all || n_total < 1 || world < 1) return EMME_EINVAL;
+    const size_t m = (size_t)emme_gather_slots(n_total, world);
+    for (int k = 0; k < n_total; ++k) {
+        const int rk = k % world;
+        const size_t slot = (size_t)rk * m + (size_t)(k / world);
+        roots_all[2 * k] = all[4 * slot + 0];
+        roots_all[2 * k + 1] = all[4 * slot + 1];
+        iters_all[k] = (int)all[4 * slot + 2];
+        info_all[k] = (int)all[4 * slot + 3];
+    }
+    return EMME_OK;
+}
+
+// 0 when RCCL can be bound in this process (not a collective: every rank asks for itself BEFORE the collective
+// emme_comm_create, so that all ranks can agree on a fall-back instead of some of them waiting in ncclCommInitRank)
+int emme_comm_available(void) { return rccl_or_error() ? EMME_OK : EMME_EDEVICE; }
+
 int emme_comm_unique_id(unsigned char* id) {
     if (!id) return EMME_EINVAL;
     Rccl* r = rccl_or_error();
@@ -148,18 +202,16 @@ int emme_gather_roots(emme_comm_t* c, void* hip_stream, const double* roots, con
                       int* info_all) {
     if (!c || !roots || !iters || !info || !roots_all || !iters_all || !info_all || n_total < 1 || n_local < 0)
         return EMME_EINVAL;
-    // the deal is fixed: item k belongs to rank k mod world.  Checked BEFORE the collective: a rank
-    // with a different idea of its share would enter the all-gather with the wrong count
-    const int mine = (n_total - c->rank + c->world - 1) / c->world;
-    if (n_local != (c->rank < n_total ? mine : 0)) {
-        emme::set_error("emme_gather_roots: n_local does not match the round-robin share of this rank");
-        return EMME_EINVAL;
+    const size_t m = (size_t)emme_gather_slots(n_total, c->world);  // slots per rank (largest share)
+    std::vector<double> pack(m * 4);
+    {   // the share is checked here, BEFORE the collective
+        const int rc = emme_gather_pack(c->rank, c->world, roots, iters, info, n_local, n_total, pack.data());
+        if (rc != EMME_OK) return rc;
     }
     Rccl* r = rccl_or_error();
     if (!r) return EMME_EDEVICE;
     if (hipSetDevice(c->device) != hipSuccess) return EMME_EDEVICE;
     hipStream_t st = (hipStream_t)hip_stream;
-    const size_t m = (size_t)(n_total + c->world - 1) / c->world;  // slots per rank (largest share)
     if (m > c->cap) {
         if (c->d_send) (void)hipFree(c->d_send);
         if (c->d_recv) (void)hipFree(c->d_recv);
@@ -171,13 +223,6 @@ int emme_gather_roots(emme_comm_t* c, void* hip_stream, const double* roots, con
         }
         c->cap = m;
     }
-    std::vector<double> pack(m * 4, std::numeric_limits<double>::quiet_NaN());
-    for (int k = 0; k < n_local; ++k) {
-        pack[4 * (size_t)k + 0] = roots[2 * k];
-        pack[4 * (size_t)k + 1] = roots[2 * k + 1];
-        pack[4 * (size_t)k + 2] = (double)iters[k];
-        pack[4 * (size_t)k + 3] = (double)info[k];
-    }
     std::vector<double> all(m * 4 * c->world);
     if (hipMemcpyAsync(c->d_send, pack.data(), pack.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
         return EMME_EDEVICE;
@@ -188,15 +233,7 @@ int emme_gather_roots(emme_comm_t* c, void* hip_stream, const double* roots, con
         emme::set_error("copy of the gathered roots failed");
         return EMME_EDEVICE;
     }
-    for (int k = 0; k < n_total; ++k) {
-        const int rk = k % c->world;
-        const size_t slot = (size_t)rk * m + (size_t)(k / c->world);
-        roots_all[2 * k] = all[4 * slot + 0];
-        roots_all[2 * k + 1] = all[4 * slot + 1];
-        iters_all[k] = (int)all[4 * slot + 2];
-        info_all[k] = (int)all[4 * slot + 3];
-    }
-    return EMME_OK;
+    return emme_gather_unpack(c->world, n_total, all.data(), roots_all, iters_all, info_all);
 }
 
 }  // extern "C"

@@ -256,6 +256,19 @@ void emme_comm_destroy(emme_comm_t* comm);
 int emme_gather_roots(emme_comm_t* comm, void* hip_stream, const double* roots /* 2*n_local */,
                       const int* iters, const int* info, int n_local, int n_total,
                       double* roots_all /* 2*n_total */, int* iters_all, int* info_all);
+/* 0 if RCCL can be bound in this process.  NOT a collective: every rank asks before emme_comm_create, so that all
+ * ranks can agree (e.g. an all-reduce over an existing process group) on the C-ABI gather or on a fall-back. */
+int emme_comm_available(void);
+/* The slot mapping emme_gather_roots uses, host only (no RCCL, no device): m = emme_gather_slots = ceil(n_total /
+ * world) slots of 4 doubles {w_re, w_im, iters, info} per rank; emme_gather_share = items of `rank` in the
+ * round-robin deal; emme_gather_pack fills a rank's 4 m doubles (NaN padded; EMME_EINVAL unless n_local is the
+ * rank's share); emme_gather_unpack turns the world * 4 m doubles of the all-gather into item order. */
+int emme_gather_slots(int n_total, int world);
+int emme_gather_share(int n_total, int world, int rank);
+int emme_gather_pack(int rank, int world, const double* roots, const int* iters, const int* info, int n_local,
+                     int n_total, double* send /* 4 * slots */);
+int emme_gather_unpack(int world, int n_total, const double* all /* world * 4 * slots */, double* roots_all,
+                       int* iters_all, int* info_all);
 
 #ifdef __cplusplus
 }
