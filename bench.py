@@ -88,10 +88,18 @@ def workload_dict(npoints=256, **over):
 
 
 def lattice(world, rank, per_gpu=128):
+    """This rank's share of the weak-scaling lattice: 16 values of Re w x (per_gpu / 16) * world values of Im w.
+    The deal is SKEWED: lattice point (row, col) goes to rank (row + col) mod world.  A plain round-robin over the
+    row-major list gives a rank the same Re columns in every row (16 is a multiple of 2, 4, 8) -- and the chains that
+    never converge start in a few of those columns (Re w = -1.2 above all): measured on one GPU, share after share
+    (tools/scaling_prediction.py, profiles/r03_scaling_prediction.json), the slowest of 8 plain shares takes 2.4x the
+    mean.  Seen from the C ABI this is still its round-robin deal (item k -> rank k mod world) of an item list in
+    which the shares are interleaved; for world = 1 the list is the row-major lattice."""
     re = np.linspace(-1.2, -0.4, 16)
     im = np.linspace(0.05, 0.40, (per_gpu // 16) * world)
-    g = (re[None, :] + 1j * im[:, None]).reshape(-1)
-    return g[rank::world].copy()
+    row, col = np.divmod(np.arange(len(re) * len(im)), len(re))
+    mine = (row + col) % world == rank
+    return (re[col[mine]] + 1j * im[row[mine]]).copy()
 
 
 def lattice_cfg4(share):
