@@ -86,6 +86,7 @@ class Options(C.Structure):
         ("union_sel", C.c_int), ("union_ipg_few", C.c_int), ("union_few_chunks", C.c_int),
         ("coop_wide_min", C.c_int), ("defer_one_group", C.c_int),
         ("dense_min_cols", C.c_int), ("dense_min_tasks", C.c_int), ("dense_cost_ratio", C.c_double),
+        ("dense_wide", C.c_int),
         ("skip_lost", C.c_int),
         ("lu_split", C.c_int), ("lu_group_min_n", C.c_int), ("lu_spin_limit", C.c_int),
         ("lu_unblocked", C.c_int),

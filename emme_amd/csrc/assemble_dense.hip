@@ -217,6 +217,8 @@ struct DenseArgs {
     const unsigned char* tile_poison[2];  // per contour class: tiles that hold a poisoned (pair, interval) block
     int dense_min_cols;         // columns that must need an interval for the MFMA path
     int skip_lost;              // columns whose matrix is already flagged (status) are left alone
+    int chunk0;                 // first chunk of this launch
+    unsigned int* overflow;     // [nbatch] integrals handed over because a level list was full (null: not counted)
 };
 
 // ---- the fill: level by level ----------------------------------------------------------------------
@@ -243,6 +245,12 @@ __device__ __forceinline__ double fsqrt_pos(double x) {
 #define EMME_DENSE_MIN_WAVES 2
 #endif
 
+// LW: words of a level list -- 64 LW entries per level.  LW = 1 is the kernel of every ordinary omega.  The trees of
+// an omega far below the real axis (Im omega = -6.7: 317 intervals per integral, 78 of them on one level) do not fit
+// 64 entries: their elements used to be handed, one by one, to the cooperative kernel -- all 32 640 integrals of the
+// omega, every Newton step (5 ms per step for two such chains).  The host sends the chunks of such omegas to the
+// LW = 2 build (128 entries, 128-bit element masks: 20 more vector registers, a launch of its own).
+template <int LW>
 __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(DenseArgs A) {
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
@@ -252,8 +260,8 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     // their tasks are the longest: chunk-major, so that they all start at once and the cheap ones fill in
     const int ntiles = (A.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;  // tile groups: 4 tiles (one per wave) per workgroup
-    const int chunk = blockIdx.x / ntg;
-    const int tile = (blockIdx.x - chunk * ntg) * 4 + wave;
+    const int chunk = A.chunk0 + blockIdx.x / ntg;
+    const int tile = (blockIdx.x - (chunk - A.chunk0) * ntg) * 4 + wave;
     // Counters leave the workgroup once: its waves add them up in LDS and the last one to finish carries the
     // sums to memory.  (Every wave of a launch adds to the same <= 128 interval counters and four round
     // counters: at one global atomic per lane -- 1.2 million per launch -- the launch waited for them, 10 % of
@@ -324,14 +332,16 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         return reinterpret_cast<const double*>(((unsigned long long)hi << 32) | lo);
     };
     // ---- the wave's 256 integrals: element r of this lane = (pair tile*16 + rho + 4 r, omega col) -----
-    unsigned long long mcur[4], mnext[4];  // entries of the current / next level this element needs
+    unsigned long long mcur[4][LW], mnext[4][LW];  // entries of the current / next level this element needs
     // per-element accumulators live in LDS (touched only by their owner lane, only when the element owns
     // the entry): 28 VGPRs less per lane, which is what lets a third wave onto the SIMD
     __shared__ double s_sumx[4][4][64], s_sumy[4][4][64], s_abstol[4][4][64];
     __shared__ int s_count[4][4][64];
     bool deferred[4], alive[4];
     // level lists: entry e of a level = (contour class << 62 | path) in lane e of (E_lo, E_hi)
-    unsigned int ecur_lo = 0, ecur_hi = 0, enext_lo = 0, enext_hi = 0;
+    unsigned int ecur_lo[LW], ecur_hi[LW], enext_lo[LW], enext_hi[LW];
+#pragma unroll
+    for (int q = 0; q < LW; ++q) ecur_lo[q] = 0, ecur_hi[q] = 0, enext_lo[q] = 0, enext_hi[q] = 0;
     int n_cur = 0;
     {
         // level 0: the root interval, once per contour class present among this chunk's omegas
@@ -340,14 +350,15 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         if (c0) e_of_cls[0] = n_cur++;
         if (c1) e_of_cls[1] = n_cur++;
         if (c1) {
-            ecur_hi = lane == e_of_cls[1] ? (1u << 30) : ecur_hi;
+            ecur_hi[0] = lane == e_of_cls[1] ? (1u << 30) : ecur_hi[0];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pidx = tile * TILE_PAIRS + rho + 4 * r;
             alive[r] = has_w && pidx < A.npairs;
-            mcur[r] = alive[r] ? (1ull << e_of_cls[cls]) : 0ull;
-            mnext[r] = 0ull;
+#pragma unroll
+            for (int q = 0; q < LW; ++q) mcur[r][q] = 0ull, mnext[r][q] = 0ull;
+            mcur[r][0] = alive[r] ? (1ull << e_of_cls[cls]) : 0ull;
             s_abstol[wave][r][lane] = 0.0, s_sumx[wave][r][lane] = 0.0, s_sumy[wave][r][lane] = 0.0;
             s_count[wave][r][lane] = 0, deferred[r] = false;
         }
@@ -366,7 +377,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         const unsigned int slot = atomicAdd(A.worklist_count, 1u);
         A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)(tile * TILE_PAIRS + rho + 4 * r);
         A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)ccls << 55) | (path & 0x7fffffffffffffull);
-        deferred[r] = true, alive[r] = false, mcur[r] = 0ull, mnext[r] = 0ull;
+        deferred[r] = true, alive[r] = false;
+#pragma unroll
+        for (int q = 0; q < LW; ++q) mcur[r][q] = 0ull, mnext[r][q] = 0ull;
     };
 
     // Poisoned blocks (k_node_cache_tiled: a folded amplitude that is not representable -- a handful of pairs with a
@@ -384,13 +397,14 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
         int n_next = 0;
         for (int e = 0; e < n_cur; ++e) {
             STAMP(ts0);
-            const unsigned int elo = (unsigned)__builtin_amdgcn_readlane((int)ecur_lo, e);
-            const unsigned int ehi = (unsigned)__builtin_amdgcn_readlane((int)ecur_hi, e);
+            // (entry e: lane e & 63 of word e >> 6 -- e is wave-uniform)
+            const unsigned int elo = (unsigned)__builtin_amdgcn_readlane((int)(LW > 1 && e >= 64 ? ecur_lo[LW - 1] : ecur_lo[0]), e & 63);
+            const unsigned int ehi = (unsigned)__builtin_amdgcn_readlane((int)(LW > 1 && e >= 64 ? ecur_hi[LW - 1] : ecur_hi[0]), e & 63);
             const int ccls = (int)(ehi >> 30);
             const unsigned long long path = (((unsigned long long)(ehi & 0x3fffffffu)) << 32) | elo;
             bool match[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) match[r] = ((mcur[r] >> e) & 1ull) != 0ull;
+            for (int r = 0; r < 4; ++r) match[r] = (((LW > 1 && e >= 64 ? mcur[r][LW - 1] : mcur[r][0]) >> (e & 63)) & 1ull) != 0ull;
             const unsigned long long need = __ballot(match[0] || match[1] || match[2] || match[3]);
             if (need == 0ull) continue;  // (its owners were deferred meanwhile)
             // slot of the interval in the cache and its record block for this tile (CacheGeom::slot, one subtree
@@ -592,15 +606,27 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 }
             }
             if (__ballot(split[0] || split[1] || split[2] || split[3]) != 0ull) {
-                if (n_next + 2 <= 64) {
+                if (n_next + 2 <= 64 * LW) {
                     const unsigned long long c0 = path << 1;
                     const unsigned int hi = ((unsigned)ccls << 30) | (unsigned)(c0 >> 32);
                     // (values and positions are wave-uniform: a lane-select writes lane n_next / n_next + 1)
-                    enext_lo = lane == n_next ? (unsigned)c0 : (lane == n_next + 1 ? (unsigned)(c0 | 1ull) : enext_lo);
-                    enext_hi = (lane == n_next || lane == n_next + 1) ? hi : enext_hi;
+                    // (n_next is even: both children land in the same word)
+                    const int nl = n_next & 63;
+                    if (LW > 1 && n_next >= 64) {
+                        enext_lo[LW - 1] = lane == nl ? (unsigned)c0 : (lane == nl + 1 ? (unsigned)(c0 | 1ull) : enext_lo[LW - 1]);
+                        enext_hi[LW - 1] = (lane == nl || lane == nl + 1) ? hi : enext_hi[LW - 1];
+                    } else {
+                        enext_lo[0] = lane == nl ? (unsigned)c0 : (lane == nl + 1 ? (unsigned)(c0 | 1ull) : enext_lo[0]);
+                        enext_hi[0] = (lane == nl || lane == nl + 1) ? hi : enext_hi[0];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (split[r]) mnext[r] |= 3ull << n_next;
+                        if (split[r]) {
+                            if (LW > 1 && n_next >= 64)
+                                mnext[r][LW - 1] |= 3ull << nl;
+                            else
+                                mnext[r][0] |= 3ull << nl;
+                        }
                     n_next += 2;
                 } else {
                     // the next level's list is full: these integrals restart in the cooperative kernel
@@ -609,13 +635,14 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         if (split[r]) {
                             defer(r, depth, ccls, path);
                             if (A.stats) atomicAdd(&A.stats[10], 1ull);
+                            if (A.overflow) atomicAdd(&A.overflow[b], 1u);  // (the host widens this omega's lists next time)
                         }
                 }
             }
 #ifdef EMME_DENSE_STAMPS
             {
                 int dep2;
-                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep2) : "v"((int)(unsigned)mnext[0]));
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(dep2) : "v"((int)(unsigned)mnext[0][0]));
                 STAMP(ts3);
                 cyc_sel += ts1 - ts0;
                 if (dense_round) cyc_dense += ts2 - ts1, cyc_dec += ts3 - ts2;
@@ -623,10 +650,13 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             }
 #endif
         }
-        ecur_lo = enext_lo, ecur_hi = enext_hi;
+#pragma unroll
+        for (int q = 0; q < LW; ++q) ecur_lo[q] = enext_lo[q], ecur_hi[q] = enext_hi[q];
         n_cur = n_next;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mcur[r] = mnext[r], mnext[r] = 0ull;
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < LW; ++q) mcur[r][q] = mnext[r][q], mnext[r][q] = 0ull;
     }
 
     // ---- results (include/solver.h:448-455: mat(i,j) = -kappa W_ij dx, mirrored) ---------------------
@@ -740,7 +770,7 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
                                  const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
                                  unsigned long long* defer_info, const int* act_idx, int n_act,
                                  const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream,
-                                 const unsigned char* const tile_poison[2]) {
+                                 const unsigned char* const tile_poison[2], int n_wide, unsigned int* overflow) {
     DenseArgs A;
     A.tile_poison[0] = tile_poison ? tile_poison[0] : nullptr;
     A.tile_poison[1] = tile_poison ? tile_poison[1] : nullptr;
@@ -771,9 +801,17 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.stats = stats;
     A.dense_min_cols = L.dense_min_cols;
     A.skip_lost = L.skip_lost;
+    A.chunk0 = 0;
+    A.overflow = overflow;
     const int ntiles = (L.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;
-    hipLaunchKernelGGL(k_assemble_dense, dim3((unsigned)((long)ntg * A.nchunks)), dim3(256), 0, stream, A);
+    // the first n_wide chunks (omegas whose level lists overflowed last time) through the 128-entry build
+    if (n_wide > A.nchunks) n_wide = A.nchunks;
+    if (n_wide > 0) hipLaunchKernelGGL(k_assemble_dense<2>, dim3((unsigned)((long)ntg * n_wide)), dim3(256), 0, stream, A);
+    if (A.nchunks > n_wide) {
+        A.chunk0 = n_wide;
+        hipLaunchKernelGGL(k_assemble_dense<1>, dim3((unsigned)((long)ntg * (A.nchunks - n_wide))), dim3(256), 0, stream, A);
+    }
     return hipGetLastError();
 }
 

@@ -103,6 +103,9 @@ struct emme_ctx {
     unsigned long long* p_iv = nullptr;  // count, WRITTEN BY KERNELS (k_retire, k_newton_update): the
     double* p_w = nullptr;         // Newton loop reads them after its one synchronisation per step
     unsigned int* p_deferred = nullptr;
+    unsigned int* d_overflow = nullptr;  // per item: integrals that left the dense fill because a level list was full
+    unsigned int* p_overflow = nullptr;  // ... published by k_retire
+    std::vector<unsigned char> h_wide;   // items whose chunks take the 128-entry build of the dense fill (root search)
     int p_cap = 0;
     bool pub_valid = false;        // last_deferred holds the previous fill's count (from p_deferred)
     int* p_lists = nullptr;        // pinned staging of the per-launch lists (omega order | chunks), two
@@ -238,6 +241,7 @@ void options_default(emme_options_t& o) {
     o.dense_min_cols = 3;
     o.dense_min_tasks = 2000;
     o.dense_cost_ratio = 4.0;
+    o.dense_wide = 0;
     o.skip_lost = 1;
     o.lu_split = 0;
     o.lu_group_min_n = 256;
@@ -272,6 +276,7 @@ void options_env_overrides(emme_options_t& o) {
     geti("EMME_DENSE_MIN_COLS", o.dense_min_cols);
     geti("EMME_DENSE_MIN_TASKS", o.dense_min_tasks);
     getd("EMME_DENSE_COST_RATIO", o.dense_cost_ratio);
+    geti("EMME_DENSE_WIDE", o.dense_wide);
     geti("EMME_SKIP_LOST", o.skip_lost);
     geti("EMME_LU_SPLIT", o.lu_split);
     if (const char* e = std::getenv("EMME_LU_GROUP")) o.lu_group_min_n = std::atoi(e) <= 0 ? -1 : std::atoi(e);
@@ -358,8 +363,10 @@ int ensure_batch(emme_ctx* c, int nb) {
         p = nullptr;
     };
     F(c->d_omega), F(c->d_domega), F(c->d_tr), F(c->d_active), F(c->d_iters), F(c->d_info),
-        F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks);
+        F(c->d_status), F(c->d_intervals), F(c->d_actidx), F(c->d_chunks), F(c->d_overflow);
     c->cap = 0;
+    HIP_TRY(malloc_retry((void**)&c->d_overflow, sizeof(unsigned int) * nb));
+    HIP_TRY(hipMemset(c->d_overflow, 0, sizeof(unsigned int) * nb));
     HIP_TRY(malloc_retry((void**)&c->d_omega, sizeof(double) * 2 * nb));
     HIP_TRY(malloc_retry((void**)&c->d_domega, sizeof(double) * 2 * nb));
     HIP_TRY(malloc_retry((void**)&c->d_tr, sizeof(double) * 2 * nb));
@@ -375,7 +382,11 @@ int ensure_batch(emme_ctx* c, int nb) {
         if (c->p_iv) (void)hipHostFree(c->p_iv);
         if (c->p_w) (void)hipHostFree(c->p_w);
         if (c->p_lists) (void)hipHostFree(c->p_lists);
+        if (c->p_overflow) (void)hipHostFree(c->p_overflow);
         c->p_act = nullptr, c->p_iv = nullptr, c->p_w = nullptr, c->p_lists = nullptr, c->p_cap = 0, c->p_lists_cap = 0;
+        c->p_overflow = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->p_overflow, sizeof(unsigned int) * nb));
+        std::memset(c->p_overflow, 0, sizeof(unsigned int) * nb);
         HIP_TRY(hipHostMalloc((void**)&c->p_act, sizeof(int) * nb));
         HIP_TRY(hipHostMalloc((void**)&c->p_iv, sizeof(unsigned long long) * nb));
         HIP_TRY(hipHostMalloc((void**)&c->p_w, sizeof(double) * 2 * nb));
@@ -709,6 +720,13 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     // similar cost (interval count of their previous assembly) together.
     if (cost)
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    // omegas whose level lists overflowed in their previous fill (root search only): first, a chunk each, through the
+    // wide-list build of the dense fill
+    int n_wide = 0;
+    if (newton_loop && c->tiled && !c->h_wide.empty()) {
+        std::stable_partition(idx.begin(), idx.end(), [&](int b) { return c->h_wide[b] != 0; });
+        for (int b : idx) n_wide += c->h_wide[b] != 0;
+    }
     // contour classes present among the omegas (needs their host values)
     // The cache costs a few hundred ms of kernels plus the allocation of up to ~170 GB to build
     // and pays off after ~10 fills: a call with a handful of omegas (a single root of a
@@ -803,6 +821,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             }
             const double dense_ratio = c->opt.dense_cost_ratio;
             size_t q = 0;
+            for (; q < (size_t)n_wide; ++q) ch.push_back((int)q), ch.push_back(1);
             while (q < idx.size()) {
                 int cap = c->tiled ? dense_cap : gw;
                 while ((!union_walk || c->tiled) && cap > (c->tiled ? 2 : 1) &&
@@ -872,7 +891,8 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                 }
                 HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
-                                              c->d_chunks, nchunks, c->d_rounds, c->stream, c->d_tile_poison));
+                                              c->d_chunks, nchunks, c->d_rounds, c->stream, c->d_tile_poison,
+                                              c->opt.dense_wide ? nchunks : n_wide, newton_loop ? c->d_overflow : nullptr));
                 if (stamps) {
                     HIP_TRY(hipEventRecord(e1, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1117,6 +1137,8 @@ void emme_ctx_destroy(emme_ctx_t* c) {
     if (c->p_w) (void)hipHostFree(c->p_w);
     if (c->p_lists) (void)hipHostFree(c->p_lists);
     if (c->p_deferred) (void)hipHostFree(c->p_deferred);
+    if (c->p_overflow) (void)hipHostFree(c->p_overflow);
+    F(c->d_overflow);
     F(c->d_worklist), F(c->d_worklist_count), F(c->d_defer_info);
     for (auto& s : c->spans) (void)hipEventDestroy(s.a), (void)hipEventDestroy(s.b);
     for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -1478,6 +1500,8 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(int) * n, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_omega, w0.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_domega, dw.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    c->h_wide.assign(n, 0);
+    HIP_TRY(hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * n, c->stream));
     std::vector<int> act(n, 1);
     std::vector<double> h_w(2 * (size_t)n);
     std::vector<unsigned long long> iv_prev(n, 0), iv_now(n, 0), cost(n, 0), iv_prev_dbg(n, 0);
@@ -1512,6 +1536,8 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         for (int b = 0; b < n; ++b) {
             act[b] = c->p_act[b];
             iv_now[b] = c->p_iv[b];
+            // (an eighth of its integrals did not fit the 64-entry level lists: 128 entries from now on)
+            if (c->p_overflow[b] * 8u >= (unsigned)c->npairs) c->h_wide[b] = 1;
             c->last_deferred = *c->p_deferred, c->pub_valid = true;
             if (iv_now[b] != iv_prev[b]) cost[b] = iv_now[b] - iv_prev[b];
             iv_prev[b] = iv_now[b];
@@ -1567,7 +1593,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
         {
             ScopedSpan s(c, K_OTHER);
             HIP_TRY(launch_retire(n, c->d_active, c->stream, c->p_act, c->d_intervals, c->p_iv,
-                                  c->d_worklist_count, c->p_deferred));
+                                  c->d_worklist_count, c->p_deferred, c->d_overflow, c->p_overflow));
         }
         pending = true, j_pending = j;
     }

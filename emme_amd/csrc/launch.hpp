@@ -10,7 +10,7 @@ namespace emme {
 // tree down to depth dfull plus up to NODE_CACHE_MAX_SUB full subtrees (root depth rd, root
 // path rp, down to depth dd).  Subtree 0 shares the main buffer with the full tree; the others
 // are added at run time, each in its own buffer.
-constexpr int NODE_CACHE_MAX_SUB = 6;
+constexpr int NODE_CACHE_MAX_SUB = 12;
 struct NodeCacheGeom {
     int dfull;
     int nsub;
@@ -111,7 +111,8 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
                                  const void* btab, unsigned long long* worklist, unsigned int* worklist_count,
                                  unsigned long long* defer_info, const int* act_idx, int n_act,
                                  const void* chunks, int nchunks, unsigned long long* stats, hipStream_t stream,
-                                 const unsigned char* const tile_poison[2] = nullptr);
+                                 const unsigned char* const tile_poison[2] = nullptr, int n_wide = 0,
+                                 unsigned int* overflow = nullptr);
 
 // tr(A_b^-1 B_b) by partial-pivot LU of the augmented system [A | B]; A, B destroyed.
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
@@ -172,7 +173,8 @@ hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, dou
 // counters and the deferred-integral count for the host to read after its next synchronisation
 hipError_t launch_retire(int nbatch, int* active, hipStream_t stream, int* pub_active = nullptr,
                          const unsigned long long* intervals = nullptr, unsigned long long* pub_intervals = nullptr,
-                         const unsigned int* deferred = nullptr, unsigned int* pub_deferred = nullptr);
+                         const unsigned int* deferred = nullptr, unsigned int* pub_deferred = nullptr,
+                         unsigned int* overflow = nullptr, unsigned int* pub_overflow = nullptr);
 // small integer lists from a pinned host block to device memory: dst1 <- src[0..n1), dst2 <- src[n1..n1+n2)
 hipError_t launch_stage_ints(const int* src_pinned, int* dst1, int n1, int* dst2, int n2, hipStream_t stream);
 

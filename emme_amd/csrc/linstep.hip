@@ -205,10 +205,15 @@ __global__ void k_newton_update(int nbatch, const double2* tr, double2* omega, d
 // synchronisation -- the active flags, the interval counters and the number of integrals the fill
 // deferred -- goes straight into its pinned memory (one kernel instead of three small copies)
 __global__ void k_retire(int nbatch, int* active, int* pub_active, const unsigned long long* intervals,
-                         unsigned long long* pub_intervals, const unsigned int* deferred, unsigned int* pub_deferred) {
+                         unsigned long long* pub_intervals, const unsigned int* deferred, unsigned int* pub_deferred,
+                         unsigned int* overflow, unsigned int* pub_overflow) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && pub_deferred) *pub_deferred = deferred ? *deferred : 0u;
     if (b >= nbatch) return;
+    if (overflow) {  // integrals of this item that left the dense fill because a level list was full: published, reset
+        if (pub_overflow) pub_overflow[b] = overflow[b];
+        overflow[b] = 0u;
+    }
     int a = active[b];
     if (a == 2) active[b] = a = 0;
     if (pub_active) pub_active[b] = a;
@@ -280,9 +285,10 @@ hipError_t launch_newton_update(int nbatch, const double* tr, double* omega, dou
 
 hipError_t launch_retire(int nbatch, int* active, hipStream_t stream, int* pub_active,
                          const unsigned long long* intervals, unsigned long long* pub_intervals,
-                         const unsigned int* deferred, unsigned int* pub_deferred) {
+                         const unsigned int* deferred, unsigned int* pub_deferred, unsigned int* overflow,
+                         unsigned int* pub_overflow) {
     hipLaunchKernelGGL(k_retire, dim3((nbatch + 63) / 64), dim3(64), 0, stream, nbatch, active, pub_active,
-                       intervals, pub_intervals, deferred, pub_deferred);
+                       intervals, pub_intervals, deferred, pub_deferred, overflow, pub_overflow);
     return hipGetLastError();
 }
 

@@ -96,6 +96,8 @@ typedef struct emme_options {
     int dense_min_cols;       /* dense fill: omega columns that must need an interval for the MFMA path   */
     int dense_min_tasks;      /* dense fill: chunk capacity is halved while a launch has fewer tile tasks */
     double dense_cost_ratio;  /* dense fill: a chunk ends where an omega costs less than 1/ratio of its first */
+    int dense_wide;           /* dense fill, level lists of 128 instead of 64 entries: 0 = for the omegas of a root search
+                                 whose lists overflowed in their previous fill, 1 = always (tests)                */
     int skip_lost;            /* 1: integrals of a matrix that already holds a non-finite entry are skipped */
     /* ---- Newton linear step ---- */
     int lu_split;             /* workgroups per matrix: 0 = by live matrices and order, k = k             */

@@ -431,6 +431,8 @@ def _modes(emme):
         "cached-dense-all-mfma": dict(node_cache_gb=8.0, wl_min=1, dense_min_cols=1),
         "cached-dense-narrow": dict(node_cache_gb=8.0, wl_min=1, dense_min_tasks=100000000),
         "cached-dense-tiny": dict(node_cache_gb=0.002, wl_min=1, cache_min_depth=1),
+        # 128-entry level lists (the build omegas with very wide trees are sent to)
+        "cached-dense-wide": dict(node_cache_gb=8.0, wl_min=1, dense_wide=1),
         "cached-union": dict(node_cache_gb=8.0, wl_min=1, fill=U),
         "cached-union-tiny": dict(node_cache_gb=0.002, wl_min=1, fill=U, cache_min_depth=1),
         # the same with the independent-lane kernel for every case
@@ -450,6 +452,7 @@ def _modes(emme):
 
 
 KERNEL_MODES = ["cached", "cached-dense-all-sparse", "cached-dense-all-mfma", "cached-dense-narrow", "cached-dense-tiny",
+                "cached-dense-wide",
                 "cached-union", "cached-union-tiny", "cached-independent", "cached-unfolded", "cached-em-per-moment",
                 "cached-tiny", "cached-tiny-independent", "omega-lane", "nodes"]
 

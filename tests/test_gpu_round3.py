@@ -269,3 +269,27 @@ def test_lost_matrix_is_left_alone_and_its_chain_retires(emme):
     assert np.abs(r1[keep] - r0[keep]).max() <= 1e-12
     print(f"deferred pass per search: {t1:.2f} ms with skip_lost, {t0:.2f} ms without; intervals {iv1} vs {iv0}")
     assert iv1 < iv0 and t1 < 0.6 * t0
+
+
+def test_wide_level_lists_for_omegas_far_below_the_axis(emme, oracle):
+    """Im omega = -6.7 (where one chain of the 4-GPU weak-scaling lattice ends): 317 intervals per integral, 78 of them
+    on one bisection level -- more than the dense fill's 64-entry level lists hold.  In a root search the omega's
+    integrals leave the dense fill in its first fill (cooperative kernel) and take the 128-entry build from then on;
+    forced here for a plain assembly (dense_wide = 1) and compared with the 64-entry build (which hands them over)
+    and the oracle: same interval counts, same entries."""
+    d = example_tokamak(npoints=48)
+    po = oracle.params(d)
+    ws = np.array([-2.6977 - 6.7337j, -1.9019 - 3.7784j, -0.8 + 0.25j])
+    with _ctx(emme, d, node_cache_gb=8.0, dense_wide=1) as ctx:
+        ctx.cache_settle(ws)
+        Mw, ivw = ctx.assemble(ws, want_intervals=True)
+    with _ctx(emme, d, node_cache_gb=8.0) as ctx:
+        ctx.cache_settle(ws)
+        Mn, ivn = ctx.assemble(ws, want_intervals=True)
+    assert np.array_equal(ivw, ivn)
+    for k, w in enumerate(ws):
+        Mo, tot = oracle.assemble(po, complex(w))
+        noise = np.abs(oracle.assemble(po, complex(w) * (1 + 1e-13))[0] - Mo).max()
+        tol = max(TOL_M * np.abs(Mo).max(), 10.0 * noise)
+        assert ivw[k] == tot
+        assert np.abs(Mw[k] - Mo).max() <= tol and np.abs(Mn[k] - Mo).max() <= tol, (w, np.abs(Mw[k] - Mo).max(), tol)
