@@ -631,8 +631,11 @@ def main():
                 out["cpu_baseline"], par = cpu_baseline(d, guesses[sample], roots, iters, sample, tol=0.0, limit=7,
                                                         budget=(10.0, 4.0))
             else:
-                # the first k_rho of this share, two of its 32 guesses (N = 512: about 1.5 s per assembly on 16 cores)
-                sample = [5, 20]
+                # the first k_rho of this share, the two of its 32 guesses whose chains are shortest on the GPU (N = 512:
+                # about 1.5 s per assembly on 16 cores; a chain the reference does not converge would take 45 s)
+                first = np.arange(len(guesses))
+                okc = first[(info[:len(guesses)] == 0) & (iters[:len(guesses)] <= d["iteration_step_limit"])]
+                sample = [int(b) for b in okc[np.argsort(iters[okc], kind="stable")][:2]]
                 out["cpu_baseline"], par = cpu_baseline(d, guesses[sample], roots, iters, sample, budget=(12.0, 5.0))
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             out["parity_sample_max_abs_err"] = par["max_abs_err"]

@@ -242,7 +242,10 @@ __device__ __forceinline__ void pivot_rows_update(int n, double2* a, double2* bb
 // is what a launch of 128 matrices of order 512 is bound by (1 GB of [M | M'], streamed from HBM per
 // panel: 34 GB per launch).  The multipliers are read from A (in-place LU layout) into LDS in chunks
 // of `rc` rows, GLS entries apart; the U rows (B operand) come from memory per tile and k-block.
-constexpr int GP = 4, GK = GP * NB, GLS = GK + 1;
+#ifndef EMME_LU_GP
+#define EMME_LU_GP 4
+#endif
+constexpr int GP = EMME_LU_GP, GK = GP * NB, GLS = GK + 1;
 // LOWER (the truncated back substitution): only tiles on or left of the diagonal of the (rows, cols) range
 // are touched, and the group's panels are applied last to first, the order of the per-panel sweep.
 template <bool LOWER = false>
