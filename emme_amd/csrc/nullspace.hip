@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include "emme_device.hpp"
 #include "launch.hpp"
@@ -26,7 +27,7 @@ namespace emme {
 
 namespace {
 
-constexpr int NT = 1024;
+constexpr int NT = 512;  // (256 vector registers per thread: the chain wave holds two 16 x 16 coefficient rows)
 constexpr int NW = NT / 64;
 constexpr int TB = 16;  // rows per block of the triangular solves
 
@@ -35,7 +36,6 @@ __device__ __forceinline__ cd ld2(const double2* p) {
     return mk(v.x, v.y);
 }
 __device__ __forceinline__ cd conj_(cd a) { return mk(a.x, -a.y); }
-__device__ __forceinline__ cd shfl_c(cd v, int src) { return mk(__shfl(v.x, src), __shfl(v.y, src)); }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -90,126 +90,133 @@ __global__ __launch_bounds__(NT) void k_null_iterate(NullArgs P) {
         for (int i = tid; i < n; i += NT) v[i] = make_double2(v[i].x * r, v[i].y * r);
         __syncthreads();
     };
-    // the 16 x 16 blocks of the triangles: lane l of wave 0 owns element k0 + l
-    // ---- z = M^-H b:  U^H w = b (forward, axpy form), L^H z' = w (backward, axpy form), z = P^T z' -------------
+    // ---- the triangular solves, pipelined over blocks of TB = 16 unknowns ------------------------------------------------
+    // One right-hand side is a chain of n dependent steps whatever one does; what can be taken OFF that chain is
+    // everything else.  Per stage (one block of 16 unknowns) the workgroup splits into
+    //   wave 0   the chain: rhs of the block's 16 equations (already updated with all blocks but the previous one),
+    //            minus the previous block's coupling (16 x 16, the previous solution still in its registers, read with
+    //            v_readlane), then the 16 x 16 triangle -- 32 readlane steps, operands from LDS;
+    //   wave 1   stages the NEXT stage's two 16 x 16 coefficient blocks from the factors (global memory) into LDS;
+    //   others   apply the PREVIOUS block's solution to all equations beyond the next block;
+    // and ONE barrier ends the stage.  (The first version had wave 0 wait for the other waves' dots and the other
+    // waves wait for wave 0's triangle, two barriers and a global-memory latency per block on the chain: 0.3 ms per
+    // sweep at n = 256, 19 ms for the 128 matrices of the headline search, eight of which are not singular and take
+    // all 60 sweeps.)
+    // coef(i, j) = coefficient of unknown j in equation i:  M(i, j) = a[rowmap[i] n + j] of the factor, or conj M(j, i)
+    // for the transposed systems; LOWER = unit diagonal (L, L^H), else divide by coef(i, i) (U, U^H).
+    double2* bA = sm + 3 * (size_t)n + ((size_t)n * sizeof(int) + 15) / 16;  // [2][TB][TB + 1] coupling with the previous block
+    double2* bD = bA + 2 * TB * (TB + 1);                                     // [2][TB][TB + 1] the block's own triangle
+    const int B = (n + TB - 1) / TB;
+    auto readlane_c = [&](cd x, int k) -> cd {
+        const long long bx = __double_as_longlong(x.x), by = __double_as_longlong(x.y);
+        const unsigned xl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bx, k), xh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bx >> 32), k);
+        const unsigned yl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)by, k), yh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(by >> 32), k);
+        return mk(__longlong_as_double((long long)(((unsigned long long)xh << 32) | xl)), __longlong_as_double((long long)(((unsigned long long)yh << 32) | yl)));
+    };
+    // x: right-hand side on entry, solution on exit (LDS, indexed by equation = unknown)
+    auto solve_tri = [&](auto trans_tag, auto lower_tag, double2* x) {
+        constexpr bool TRANS = decltype(trans_tag)::value, LOWER = decltype(lower_tag)::value;
+        constexpr bool FWD = LOWER != TRANS;
+        auto blk0 = [&](int s) { return (FWD ? s : B - 1 - s) * TB; };   // first unknown of the block of stage s
+        auto blkn = [&](int s) { return min(TB, n - blk0(s)); };
+        // stage the coefficient blocks of stage s (equations of block s x unknowns of block s - 1 / of block s)
+        auto stage_blocks = [&](int s) {
+            const int r1 = blk0(s), n1 = blkn(s);
+            const int rp = s > 0 ? blk0(s - 1) : 0, np = s > 0 ? blkn(s - 1) : 0;
+            double2* dA = bA + (s & 1) * TB * (TB + 1);
+            double2* dD = bD + (s & 1) * TB * (TB + 1);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int e = it * 64 + lane;
+                // (contiguous in memory along the fast index: columns of a row for the plain systems, rows for the transposed)
+                const int l = TRANS ? (e & 15) : (e >> 4), kk = TRANS ? (e >> 4) : (e & 15);
+                double2 va = make_double2(0.0, 0.0), vd = make_double2(0.0, 0.0);
+                if (l < n1 && kk < n1) {
+                    vd = TRANS ? a[(size_t)rowmap[r1 + kk] * n + r1 + l] : a[(size_t)rowmap[r1 + l] * n + r1 + kk];
+                    if (TRANS) vd.y = -vd.y;
+                }
+                if (l < n1 && kk < np) {
+                    va = TRANS ? a[(size_t)rowmap[rp + kk] * n + r1 + l] : a[(size_t)rowmap[r1 + l] * n + rp + kk];
+                    if (TRANS) va.y = -va.y;
+                }
+                dA[l * (TB + 1) + kk] = va, dD[l * (TB + 1) + kk] = vd;
+            }
+        };
+        if (wave == 1) stage_blocks(0);
+        __syncthreads();
+        cd xprev = mk(0.0, 0.0);  // wave 0: the previous block's solution, unknown kk in lane kk
+        for (int s = 0; s < B; ++s) {
+            const int r0 = blk0(s), nbk = blkn(s);
+            if (wave == 0) {
+                const double2* dA = bA + (s & 1) * TB * (TB + 1) + (lane & 15) * (TB + 1);
+                const double2* dD = bD + (s & 1) * TB * (TB + 1) + (lane & 15) * (TB + 1);
+                const bool on = lane < nbk;
+                cd sv = on ? mk(x[r0 + lane].x, x[r0 + lane].y) : mk(0.0, 0.0);
+                cd ca[TB], cdg[TB];
+#pragma unroll
+                for (int kk = 0; kk < TB; ++kk) ca[kk] = mk(dA[kk].x, dA[kk].y), cdg[kk] = mk(dD[kk].x, dD[kk].y);
+                if (s > 0) {
+#pragma unroll
+                    for (int kk = 0; kk < TB; ++kk) sv = sv - ca[kk] * readlane_c(xprev, kk);  // (rows beyond the block hold zeros)
+                }
+#pragma unroll
+                for (int q = 0; q < TB; ++q) {
+                    const int kk = FWD ? q : TB - 1 - q;
+                    if (kk < nbk) {  // uniform
+                        if (!LOWER && lane == kk) sv = sv * rcp(cdg[kk]);
+                        const cd xk = readlane_c(sv, kk);
+                        if (on && (FWD ? lane > kk : lane < kk)) sv = sv - cdg[kk] * xk;
+                    }
+                }
+                if (on) x[r0 + lane] = make_double2(sv.x, sv.y);
+                xprev = sv;
+            } else if (wave == 1) {
+                if (s + 1 < B) stage_blocks(s + 1);
+            } else if (s > 0) {
+                // apply the previous block's solution (final in x since the last barrier) to the equations beyond this block
+                const int rp = blk0(s - 1), np = blkn(s - 1);
+                const int lo = FWD ? r0 + nbk : 0, hi = FWD ? n : r0;  // equations [lo, hi)
+                if (!TRANS) {
+                    // 16 contiguous coefficients per equation: four equations per wave and trip, 16-lane sums
+                    const int kk = lane & 15;
+                    const cd xk = kk < np ? mk(x[rp + kk].x, x[rp + kk].y) : mk(0.0, 0.0);
+                    for (int i = lo + (wave - 2) * 4 + (lane >> 4); i < hi; i += (NW - 2) * 4) {
+                        const cd c = kk < np ? ld2(&a[(size_t)rowmap[i] * n + rp + kk]) : mk(0.0, 0.0);
+                        const cd pr = c * xk;
+                        const double sx = row16_sum(pr.x), sy = row16_sum(pr.y);
+                        if (kk == 0) x[i] = make_double2(x[i].x - sx, x[i].y - sy);
+                    }
+                } else {
+                    // coefficients of one unknown are contiguous along the equations: an equation per thread
+                    for (int i = lo + (wave - 2) * 64 + lane; i < hi; i += (NW - 2) * 64) {
+                        cd acc = mk(x[i].x, x[i].y);
+#pragma unroll
+                        for (int kk = 0; kk < TB; ++kk)
+                            if (kk < np) acc = acc - conj_(ld2(&a[(size_t)rowmap[rp + kk] * n + i])) * mk(x[rp + kk].x, x[rp + kk].y);
+                        x[i] = make_double2(acc.x, acc.y);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // z = M^-H b:  U^H w = b, L^H z' = w, z = P^T z'
     auto solve_h = [&]() {
-        for (int k0 = 0; k0 < n; k0 += TB) {
-            const int nbk = min(TB, n - k0);
-            if (wave == 0) {
-                cd u[TB];  // u[kk] = U(k0 + kk, k0 + lane)
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk)
-                    u[kk] = (kk < nbk && lane < nbk) ? ld2(&a[(size_t)rowmap[k0 + kk] * n + k0 + lane]) : mk(1.0, 0.0);
-                cd w = lane < nbk ? mk(v[k0 + lane].x, v[k0 + lane].y) : mk(0.0, 0.0);
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk) {
-                    if (kk < nbk) {
-                        if (lane == kk) w = w * rcp(conj_(u[kk]));
-                        const cd wk = shfl_c(w, kk);
-                        if (lane > kk) w = w - conj_(u[kk]) * wk;
-                    }
-                }
-                if (lane < nbk) v[k0 + lane] = make_double2(w.x, w.y);
-            }
-            __syncthreads();
-            for (int r = k0 + nbk + tid; r < n; r += NT) {
-                cd acc = mk(v[r].x, v[r].y);
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk)
-                    if (kk < nbk) acc = acc - conj_(ld2(&a[(size_t)rowmap[k0 + kk] * n + r])) * mk(v[k0 + kk].x, v[k0 + kk].y);
-                v[r] = make_double2(acc.x, acc.y);
-            }
-            __syncthreads();
-        }
-        for (int k0 = (n - 1) / TB * TB; k0 >= 0; k0 -= TB) {
-            const int nbk = min(TB, n - k0);
-            if (wave == 0) {
-                cd l[TB];  // l[kk] = L(k0 + kk, k0 + lane), lane < kk
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk)
-                    l[kk] = (kk < nbk && lane < kk) ? ld2(&a[(size_t)rowmap[k0 + kk] * n + k0 + lane]) : mk(0.0, 0.0);
-                cd z = lane < nbk ? mk(v[k0 + lane].x, v[k0 + lane].y) : mk(0.0, 0.0);
-#pragma unroll
-                for (int kk = TB - 1; kk >= 1; --kk) {
-                    if (kk < nbk) {
-                        const cd zk = shfl_c(z, kk);
-                        if (lane < kk) z = z - conj_(l[kk]) * zk;
-                    }
-                }
-                if (lane < nbk) v[k0 + lane] = make_double2(z.x, z.y);
-            }
-            __syncthreads();
-            for (int r = tid; r < k0; r += NT) {
-                cd acc = mk(v[r].x, v[r].y);
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk)
-                    if (kk < nbk) acc = acc - conj_(ld2(&a[(size_t)rowmap[k0 + kk] * n + r])) * mk(v[k0 + kk].x, v[k0 + kk].y);
-                v[r] = make_double2(acc.x, acc.y);
-            }
-            __syncthreads();
-        }
+        solve_tri(T_{}, F_{}, v);
+        solve_tri(T_{}, T_{}, v);
         for (int r = tid; r < n; r += NT) t[rowmap[r]] = v[r];
         __syncthreads();
         for (int r = tid; r < n; r += NT) v[r] = t[r];
         __syncthreads();
     };
-    // ---- y = M^-1 b:  c = P b, L c' = c (forward, dot form), U y = c' (backward, dot form) --------------------------
+    // y = M^-1 b:  c = P b, L c' = c, U y = c'
     auto solve_n = [&]() {
         for (int r = tid; r < n; r += NT) t[r] = v[rowmap[r]];
         __syncthreads();
-        for (int r0 = 0; r0 < n; r0 += TB) {
-            const int nbk = min(TB, n - r0);
-            if (wave < nbk && r0 > 0) {
-                const double2* row = a + (size_t)rowmap[r0 + wave] * n;
-                cd s = mk(0.0, 0.0);
-                for (int k = lane; k < r0; k += 64) s = s + ld2(&row[k]) * mk(t[k].x, t[k].y);
-                s.x = wave_sum(s.x), s.y = wave_sum(s.y);
-                if (lane == 0) t[r0 + wave] = make_double2(t[r0 + wave].x - s.x, t[r0 + wave].y - s.y);
-            }
-            __syncthreads();
-            if (wave == 0) {
-                cd l[TB];  // l[kk] = L(r0 + lane, r0 + kk), kk < lane
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk)
-                    l[kk] = (lane < nbk && kk < lane) ? ld2(&a[(size_t)rowmap[r0 + lane] * n + r0 + kk]) : mk(0.0, 0.0);
-                cd c = lane < nbk ? mk(t[r0 + lane].x, t[r0 + lane].y) : mk(0.0, 0.0);
-#pragma unroll
-                for (int kk = 0; kk < TB - 1; ++kk) {
-                    const cd ck = shfl_c(c, kk);
-                    if (lane > kk) c = c - l[kk] * ck;
-                }
-                if (lane < nbk) t[r0 + lane] = make_double2(c.x, c.y);
-            }
-            __syncthreads();
-        }
-        for (int r0 = (n - 1) / TB * TB; r0 >= 0; r0 -= TB) {
-            const int nbk = min(TB, n - r0);
-            if (wave < nbk && r0 + nbk < n) {
-                const double2* row = a + (size_t)rowmap[r0 + wave] * n;
-                cd s = mk(0.0, 0.0);
-                for (int k = r0 + nbk + lane; k < n; k += 64) s = s + ld2(&row[k]) * mk(t[k].x, t[k].y);
-                s.x = wave_sum(s.x), s.y = wave_sum(s.y);
-                if (lane == 0) t[r0 + wave] = make_double2(t[r0 + wave].x - s.x, t[r0 + wave].y - s.y);
-            }
-            __syncthreads();
-            if (wave == 0) {
-                cd u[TB];  // u[kk] = U(r0 + lane, r0 + kk), kk >= lane
-#pragma unroll
-                for (int kk = 0; kk < TB; ++kk)
-                    u[kk] = (lane < nbk && kk < nbk && kk >= lane) ? ld2(&a[(size_t)rowmap[r0 + lane] * n + r0 + kk]) : mk(1.0, 0.0);
-                cd y = lane < nbk ? mk(t[r0 + lane].x, t[r0 + lane].y) : mk(0.0, 0.0);
-#pragma unroll
-                for (int kk = TB - 1; kk >= 0; --kk) {
-                    if (kk < nbk) {
-                        if (lane == kk) y = y * rcp(u[kk]);
-                        const cd yk = shfl_c(y, kk);
-                        if (lane < kk) y = y - u[kk] * yk;
-                    }
-                }
-                if (lane < nbk) t[r0 + lane] = make_double2(y.x, y.y);
-            }
-            __syncthreads();
-        }
+        solve_tri(F_{}, T_{}, t);
+        solve_tri(F_{}, F_{}, t);
         for (int r = tid; r < n; r += NT) v[r] = t[r];
         __syncthreads();
     };
@@ -316,7 +323,9 @@ __global__ __launch_bounds__(NT) void k_lu_unblocked_inplace(int n, double2* A, 
 
 }  // namespace
 
-size_t null_iterate_lds(int n) { return (size_t)3 * n * sizeof(double2) + (size_t)n * sizeof(int); }
+size_t null_iterate_lds(int n) {
+    return (size_t)3 * n * sizeof(double2) + (((size_t)n * sizeof(int) + 15) / 16) * 16 + (size_t)4 * TB * (TB + 1) * sizeof(double2);
+}
 
 hipError_t launch_lu_unblocked_inplace(int n, int nbatch, double* A, int* maps, int* info, hipStream_t stream) {
     const size_t lds = (size_t)n * sizeof(double2) + (size_t)n * sizeof(int);
