@@ -157,3 +157,21 @@ def test_id_file_rendezvous_ignores_another_runs_file(tmp_path):
     assert got == [b"B" * 128]
     clear_id_file(path)
     assert not os.path.exists(path)
+
+
+def test_predicted_share_imbalance_of_the_deal():
+    """No multi-GPU node is available to the builder: the per-rank cost of the deal is MEASURED on one GPU, share after
+    share (tools/scaling_prediction.py -> profiles/r03_scaling_prediction.json), and pinned here: with the skewed
+    deal of bench.lattice the slowest share of the weak-scaling lattice stays within 1.3x the mean for 2, 4 and 8
+    ranks (plain round-robin: 2.4x at 8 ranks -- a rank then holds the same Re omega columns in every row, and the
+    chains that never converge start in a few of those columns), configs[3]'s shares within 1.05x.  The real curve
+    is the driver's SCALE_rNN.json; none has been measured (no 8-GPU node in this pool so far)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_scaling_prediction.json")
+    d = json.load(open(path))
+    lat = d["config3_headline_lattice"]
+    for world in ("2", "4", "8"):
+        assert len(lat[world]["share_ms"]) == int(world)
+        assert lat[world]["max_over_mean"] <= 1.3, (world, lat[world])
+    if "config4_shares" in d:
+        assert d["config4_shares"]["max_over_mean"] <= 1.05
