@@ -215,8 +215,11 @@ struct AllocTimer {
     bool running = true;
     explicit AllocTimer(emme_ctx* ctx) : c(ctx) {}
     void stop() {
-        if (running)
-            c->acc.cache_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (running) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            c->acc.cache_alloc_ms += ms;
+            if (std::getenv("EMME_DEBUG")) fprintf(stderr, "[emme] node cache: allocation took %.1f ms\n", ms);
+        }
         running = false;
     }
     ~AllocTimer() { stop(); }
