@@ -486,6 +486,9 @@ __global__ __launch_bounds__(256, 2) void k_assemble_cached_em(AsmCachedArgs A) 
     const double2* Moldb = A.Mold ? A.Mold + (size_t)b * dim * dim : nullptr;
     double2* Mpb = A.Mp ? A.Mp + (size_t)b * dim * dim : nullptr;
     auto store = [&](int r, int c, cd v) {
+#ifdef EMME_EM_NO_STORE  // timing experiment only (results are garbage): what the scattered 16-byte stores cost
+        if (v.x != 1.2345e300) return;
+#endif
         const size_t idx = (size_t)r * dim + c;
         Mb[idx] = make_double2(v.x, v.y);
         if (Moldb) {

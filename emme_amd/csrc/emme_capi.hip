@@ -1522,7 +1522,9 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     rc = refresh_cost();  // synchronises; the first fill's interval counts order the second
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_omega, w1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream));
-    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
+    // (the fills of a root search write M only: the secant M' = (M - M_old) / d, include/solver.h:157 and :412, is
+    // taken by k_secant_copy at the top of the step that uses it, in one coalesced pass)
+    rc = do_assemble(c, n, c->d_omega, nullptr, nullptr, c->d_M, nullptr, nullptr, nullptr,
                      cost.data(), w1.data(), true);
     if (rc) return rc;
 
@@ -1565,11 +1567,11 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
     for (int j = 0; j <= step_limit; ++j) {  // src/main.cpp:43
         const bool fused_copy = method == EMME_METHOD_TRACE_SECANT;
         {
-            // previous matrix for the secant (and the LU's work copy in the same pass), for the
-            // chains still iterating only
+            // the secant M' of the step just taken, then this step's matrix becomes the "previous" one (and the
+            // LU's work copy): one pass, for the chains still iterating only
             ScopedSpan s(c, K_OTHER);
-            HIP_TRY(launch_copy_active(c->dim, n, c->d_M, c->d_Mold, fused_copy ? c->d_work : nullptr,
-                                       c->d_active, c->stream));
+            HIP_TRY(launch_secant_copy(c->dim, n, c->d_M, c->d_Mold, fused_copy ? c->d_work : nullptr, c->d_Mp,
+                                       c->d_domega, c->d_active, c->stream));
         }
         {
             ScopedSpan s(c, K_LIN);
@@ -1590,7 +1592,7 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             for (int b = 0; b < n; ++b) any |= act[b] != 0;
             if (!any) break;  // (this step's LU and update found nothing active: no-ops)
         }
-        rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, c->d_Mold, c->d_Mp, c->d_domega,
+        rc = do_assemble(c, n, c->d_omega, c->d_active, act.data(), c->d_M, nullptr, nullptr, nullptr,
                          cost.data(), h_w.data(), true);
         if (rc) return rc;
         {

@@ -122,6 +122,11 @@ hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int
 hipError_t launch_copy_active(int n, int nbatch, const double* src, double* dst1, double* dst2,
                               const int* active, hipStream_t stream);
 
+// Mp[b] = (M[b] - Mold[b]) / domega[b], Mold[b] = M[b], work[b] = M[b] (if given) for the active matrices: the secant
+// of a Newton step (include/solver.h:157) and the copies of the next one, in one pass
+hipError_t launch_secant_copy(int n, int nbatch, const double* M, double* Mold, double* work, double* Mp,
+                              const double* domega, const int* active, hipStream_t stream);
+
 // Blocked version (linstep_blocked.hip): whole L21 panel in LDS for n <= ~560, in chunks up to 1024.
 // nwg workgroups per matrix (1: one does everything; > 1: one factors A, the others carry B's
 // columns; `items` = device list of the nitems matrices to work on, null for all of them);

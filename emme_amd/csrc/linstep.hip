@@ -262,7 +262,39 @@ __global__ __launch_bounds__(256) void k_copy_active(long elems, const double2* 
     }
 }
 
+// The secant of a Newton step for the active matrices, fused with the two copies that follow it:
+//   Mp = (M - Mold) / domega  (include/solver.h:157),  Mold = M,  work = M (if given)
+// in ONE coalesced pass.  The fill kernels used to do the secant entry by entry where they store their integrals
+// -- lanes are (pair, omega), so every Mold read and Mp write was a 16-byte access with a line to itself: at
+// dim 512 (BASELINE configs[3]) those scattered accesses were 2.0 of a fill launch's 2.9 ms.
+__global__ __launch_bounds__(256) void k_secant_copy(long elems, const double2* M, double2* Mold, double2* work,
+                                                     double2* Mp, const double2* domega, const int* active) {
+    const int b = blockIdx.y;
+    if (active && active[b] == 0) return;
+    const cd rdw = rcp(mk(domega[b].x, domega[b].y));
+    const double2* s = M + (size_t)b * elems;
+    double2* o = Mold + (size_t)b * elems;
+    double2* p = Mp + (size_t)b * elems;
+    double2* w = work ? work + (size_t)b * elems : nullptr;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < elems; e += (long)gridDim.x * blockDim.x) {
+        const double2 v = s[e], vo = o[e];
+        const cd d = (mk(v.x, v.y) - mk(vo.x, vo.y)) * rdw;
+        p[e] = make_double2(d.x, d.y);
+        o[e] = v;
+        if (w) w[e] = v;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_secant_copy(int n, int nbatch, const double* M, double* Mold, double* work, double* Mp,
+                              const double* domega, const int* active, hipStream_t stream) {
+    const long elems = (long)n * n;
+    const unsigned gx = (unsigned)std::min<long>(64, (elems + 255) / 256);
+    hipLaunchKernelGGL(k_secant_copy, dim3(gx, nbatch), dim3(256), 0, stream, elems, (const double2*)M, (double2*)Mold,
+                       (double2*)work, (double2*)Mp, (const double2*)domega, active);
+    return hipGetLastError();
+}
 
 hipError_t launch_trace_solve(int n, int nbatch, double* A, double* B, const int* active,
                               double* tr, int* info, hipStream_t stream) {
