@@ -60,26 +60,28 @@ struct TiledCacheArgs {
     CacheGeom geom;
     double omi;
     double* recs;    // [ntiles][count][TILE_BLOCK]
-    double2* ttab;   // [NI][16]  T per (interval, node lane)
+    double2* ttab;   // [NI][GW]  T per (interval, node lane)
+    double2* wtab;   // [NI][GW]  W per (interval, node lane): the moment factor of electromagnetic fills (null: none)
     double* scale;   // [NI]
     int part, first, count;
     unsigned char* tile_poison;  // [ntiles] of this contour class: 1 if any (pair, interval) block of the tile is poisoned
 };
 
-// One 16-lane group per (pair, interval), lane = node (gk_lane<15>): computes the folded record and
-// scatters it into the tile block.
+// One lane group (16 lanes for GK15, 32 for GK31) per (pair, interval), lane = node (gk_lane<PTS>): computes the
+// folded record and scatters it into the tile block.
+template <int PTS>
 __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
-    constexpr int GW = 16, GROUPS_PER_BLOCK = 256 / GW;
+    constexpr int GW = tile_slots(PTS), GROUPS_PER_BLOCK = 256 / GW, TB = tile_block_doubles(PTS);
     const DevParams& P = A.P;
     const int N = P.N, NI = A.count;
     const int lane = threadIdx.x % GW;
     const int ntiles = (A.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const long total = (long)ntiles * TILE_PAIRS * NI;
-    const GkLane gk = gk_lane<15>(lane);
+    const GkLane gk = gk_lane<PTS>(lane);
     const double* eta = A.tab;
     const double* gtab = A.tab + N;
     const double* btab = A.tab + 2 * N;
-    const int sn = slotnode_of_lane(lane);
+    const int sn = slotnode_of_lane_t<PTS>(lane);
     for (long w = (long)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / GW; w < total;
          w += (long)gridDim.x * GROUPS_PER_BLOCK) {
         // w = (tile * NI + idx) * 16 + p: the 16 pairs of a (tile, interval) block are neighbours
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
         const int idx = (int)(ti % NI);
         const long tile = ti / NI;
         const long item = tile * TILE_PAIRS + p;
-        double* blk = A.recs + ti * TILE_BLOCK;
+        double* blk = A.recs + ti * TB;
         cd q1 = mk(0.0, 0.0), q0 = mk(0.0, 0.0);
         bool over = false;
         int depth;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
             const int i = ij.x, j = ij.y;
             const PairConst pc = make_pair_const(P, eta[i], eta[j], btab[i], btab[j], gtab[i] - gtab[j]);
             const NodeData d = node_data(x, P, pc, A.omi, 0);
-            if (item < A.npairs && lane < 15) {
+            if (item < A.npairs && lane < PTS) {
                 double sa, ca;
                 sincos(d.A0.y, &sa, &ca);
                 const double ea = exp(d.A0.x);
@@ -121,15 +123,20 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
             }
             if (item == 0) {
                 A.ttab[(long)(A.first + idx) * GW + lane] = make_double2(d.T.x, d.T.y);
+                if (A.wtab) {
+                    const cd wv = node_w(x, P, A.omi);
+                    A.wtab[(long)(A.first + idx) * GW + lane] = make_double2(wv.x, wv.y);
+                }
                 if (lane == 0) A.scale[A.first + idx] = scale;
             }
         }
         // poisoned (pair, interval): all of its records are zeroed (the GEMMs of the tile's other pairs stay finite)
-        // and the padding slot [sn = 15][p][0] carries the flag -- it multiplies a zero row of the phase block
-        const bool poisoned = ((__ballot(over) >> (threadIdx.x & 48)) & 0xffffull) != 0ull;
+        // and the padding slot [sn = GW - 1][p][0] carries the flag -- it multiplies a zero row of the phase block
+        const bool poisoned = GW == 16 ? ((__ballot(over) >> (threadIdx.x & 48)) & 0xffffull) != 0ull
+                                       : ((__ballot(over) >> (threadIdx.x & 32)) & 0xffffffffull) != 0ull;
         if (poisoned) {
-            q1 = mk(lane == 15 ? 1.0 : 0.0, 0.0), q0 = mk(0.0, 0.0);
-            if (lane == 15 && A.tile_poison) A.tile_poison[tile] = 1;
+            q1 = mk(lane == GW - 1 ? 1.0 : 0.0, 0.0), q0 = mk(0.0, 0.0);
+            if (lane == GW - 1 && A.tile_poison) A.tile_poison[tile] = 1;
         }
         double2* q = reinterpret_cast<double2*>(blk);
         q[tile_index(2 * sn, p)] = make_double2(q1.x, q1.y);
@@ -140,26 +147,32 @@ __global__ __launch_bounds__(256) void k_node_cache_tiled(TiledCacheArgs A) {
 // Weighted phase tables of one launch (see node_cache.hpp: BTAB_BLOCK).
 struct BtabArgs {
     const double2* ttab[2];
+    const double2* wtab[2];  // electromagnetic fills: W per (interval, node lane)
     const double2* omega;
     const int* act_idx;
     const int* wmap;  // per position of the launch's omega list: chunk << 8 | column
     int n_act, nchunks, nslots;
     double* btab;
 };
+// Electromagnetic fills (NM = 3): the moment factor of F_m = F_0 (c_nv W)^m has a pair-independent part, W^m, which
+// belongs to the phase operand: omega position w of a chunk owns the three columns 3 w + m with wk E W^m (the
+// real factor c_nv^m of the pair is applied to the sums before the decisions, k_assemble_dense).
+template <int PTS, int NM>
 __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
-    const long total = (long)A.nslots * 16 * A.n_act;
+    constexpr int GW = tile_slots(PTS), BT = btab_block_doubles(PTS);
+    const long total = (long)A.nslots * GW * A.n_act;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         // e = (slot * 16 + lane) * n_act + wpos: neighbouring threads = neighbouring omega columns of one
         // table row, so every store instruction writes whole 128-byte row segments
         const long row = e / A.n_act;
         const int wpos = (int)(e - row * A.n_act);
-        const int lane = (int)(row & 15);
-        const int slot = (int)(row >> 4);
+        const int lane = (int)(row % GW);
+        const int slot = (int)(row / GW);
         const double2 om = A.omega[A.act_idx[wpos]];
         const int cls = -copysign(1.0, om.x) > 0.0 ? 0 : 1;
         cd ev = mk(0.0, 0.0);
-        if (A.ttab[cls] && lane < 15) {
-            const double2 t = A.ttab[cls][(long)slot * 16 + lane];
+        if (A.ttab[cls] && lane < PTS) {
+            const double2 t = A.ttab[cls][(long)slot * GW + lane];
             const double ax = fma(t.x, om.x, -(t.y * om.y)), ay = fma(t.x, om.y, t.y * om.x);
             if (!(ax > 700.0)) {  // (a NaN omega goes through and poisons its own column only)
                 double sa, ca;
@@ -173,26 +186,40 @@ __global__ __launch_bounds__(256) void k_btab(BtabArgs A) {
                 ev = mk(__builtin_nan(""), __builtin_nan(""));
             }
         }
-        const GkLane gk = gk_lane<15>(lane);
-        const int sn = slotnode_of_lane(lane);
+        const GkLane gk = gk_lane<PTS>(lane);
+        const int sn = slotnode_of_lane_t<PTS>(lane);
         const int wm = A.wmap[wpos];
-        double* blk = A.btab + ((size_t)slot * A.nchunks + (wm >> 8)) * BTAB_BLOCK;
-        const int col = wm & 255;
+        double* blk = A.btab + ((size_t)slot * A.nchunks + (wm >> 8)) * BT;
+        const int col = NM * (wm & 255);
         double2* bk = reinterpret_cast<double2*>(blk);
-        bk[sn * 16 + col] = make_double2(gk.wk * ev.x, gk.wk * ev.y);
-
+        cd bv = mk(gk.wk * ev.x, gk.wk * ev.y);
+        bk[sn * 16 + col] = make_double2(bv.x, bv.y);
+        if (NM > 1) {
+            cd wv = mk(0.0, 0.0);
+            if (A.wtab[cls] && lane < PTS) {
+                const double2 w2 = A.wtab[cls][(long)slot * GW + lane];
+                wv = mk(w2.x, w2.y);
+            }
+#pragma unroll
+            for (int m = 1; m < NM; ++m) {
+                bv = bv * wv;
+                bk[sn * 16 + col + m] = make_double2(bv.x, bv.y);
+            }
+        }
     }
 }
 
 // (wg / wk) of node slot sn: the Gauss rule's weight relative to the Kronrod weight; 0 for Kronrod-only nodes
+template <int PTS>
 __device__ __forceinline__ double gauss_ratio(int sn) {
-    if (sn > 6) return 0.0;
-    const int q = sn == 0 ? 0 : ((sn + 1) & ~1);  // slots (1,2) (3,4) (5,6) are nodes +-x2, +-x4, +-x6
-    return kWg15[q >> 1] / kWk15[q];
+    if (sn >= (PTS - 1) / 2) return 0.0;          // (7 / 15 Gauss nodes, slots 0 ..)
+    const int q = sn == 0 ? 0 : ((sn + 1) & ~1);  // slots (1,2) (3,4) (5,6) .. are nodes +-x2, +-x4, +-x6 ..
+    return PTS == 15 ? kWg15[q >> 1] / kWk15[q] : kWg31[q >> 1] / kWk31[q];
 }
 
 struct DenseArgs {
     DevParams P;
+    const double* tab;  // eta | g | b (electromagnetic fills: c_nv, kappa_e and the D diagonal)
     const ushort2* pairs;
     int npairs;
     CacheGeom geom;
@@ -250,18 +277,40 @@ __device__ __forceinline__ double fsqrt_pos(double x) {
 // 64 entries: their elements used to be handed, one by one, to the cooperative kernel -- all 32 640 integrals of the
 // omega, every Newton step (5 ms per step for two such chains).  The host sends the chunks of such omegas to the
 // LW = 2 build (128 entries, 128-bit element masks: 20 more vector registers, a launch of its own).
-template <int LW>
+//
+// PTS = 31: 32 node slots, a complex 16 x 16 x 64 GEMM per round (two batches of eight k-steps; the embedded 15-point
+// Gauss rule lives in the first).  NM = 3 (electromagnetic, include/solver.h:461-511): the three velocity moments
+// F_m = F_0 (c_nv W)^m of a pair share the records; W^m sits in the phase operand (k_btab), so a chunk is <= 5 omegas x 3
+// moments = 15 COLUMNS (column 3 w + m) of the same GEMM, every (pair, omega, moment) integral decides for itself as
+// before, and the pair's real factor c_nv^m multiplies its sums before the decision (k_assemble_cached_em walks the
+// union of the three moments' trees per lane; here they are three columns of the tile's union).
+template <int LW, int PTS, int NM>
 __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(DenseArgs A) {
+    constexpr int NS = tile_slots(PTS), KS = NS / 2, GKS = KS / 2;  // node slots, k-steps of K, k-steps that feed G too
+    constexpr int TB = tile_block_doubles(PTS), BT = btab_block_doubles(PTS);
     const DevParams& P = A.P;
     const int N = P.N, dim = P.dim;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, rho = lane >> 4;
+    const int wcol = NM == 1 ? col : col / NM;      // omega position of this lane's column in its chunk
+    const int mom = NM == 1 ? 0 : col - wcol * NM;  // its velocity moment
     // task order: the chunks of the cost-sorted omega list hold the most expensive omegas first, and
     // their tasks are the longest: chunk-major, so that they all start at once and the cheap ones fill in
     const int ntiles = (A.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;  // tile groups: 4 tiles (one per wave) per workgroup
-    const int chunk = A.chunk0 + blockIdx.x / ntg;
-    const int tile = (blockIdx.x - (chunk - A.chunk0) * ntg) * 4 + wave;
+    int chunk = A.chunk0 + blockIdx.x / ntg;
+    int tile = (blockIdx.x - (chunk - A.chunk0) * ntg) * 4 + wave;
+    if (NM > 1) {
+        // Electromagnetic launches have 3.2 times the chunks (5 omegas each) and 16-KB record blocks: in chunk-major
+        // order every chunk fetched every block of its tiles from HBM again (26 chunks x 390 MB per launch).  Here
+        // the chunks of a tile group run back to back ON ONE XCD (workgroup ids go round the eight XCDs), whose L2
+        // then serves the tile's blocks to all but the first.
+        const int nch = A.nchunks - A.chunk0;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int tg = (k / nch) * 8 + xcd;
+        chunk = A.chunk0 + k % nch;
+        tile = tg * 4 + wave;
+    }
     // Counters leave the workgroup once: its waves add them up in LDS and the last one to finish carries the
     // sums to memory.  (Every wave of a launch adds to the same <= 128 interval counters and four round
     // counters: at one global atomic per lane -- 1.2 million per launch -- the launch waited for them, 10 % of
@@ -277,8 +326,8 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     const int waves_here = min(4, ntiles - (tile - wave));  // waves of this workgroup that own a tile
 
     const int2 ch = A.chunks[chunk];
-    const bool in_chunk = col < ch.y;
-    const int wpos = ch.x + (in_chunk ? col : 0);
+    const bool in_chunk = wcol < ch.y;
+    const int wpos = ch.x + (in_chunk ? wcol : 0);
     const int b = A.act_idx[wpos];
     // A matrix that already holds a non-finite integral is lost (its chain retires at the next Newton step, as the
     // reference's does: include/solver.h:142-153): nobody works on it any more.  (The four lanes of a column read
@@ -295,17 +344,41 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             A.Mp[idx] = make_double2(d.x, d.y);
         }
     };
-    if (tile == 0 && has_w) {  // diagonal (include/solver.h:442-443)
+    if (tile == 0 && has_w && mom == 0) {  // diagonal (include/solver.h:442-443; electromagnetic: 465-470)
         const cd rdw0 = A.Mold ? rcp(mk(A.domega[b].x, A.domega[b].y)) : mk(0.0, 0.0);
-        for (int i = rho; i < N; i += 4) store(i, i, mk(P.diag_a, 0.0), rdw0);
+        for (int i = rho; i < N; i += 4) {
+            store(i, i, mk(P.diag_a, 0.0), rdw0);
+            if (NM > 1) {
+                store(i, i + N, mk(0.0, 0.0), rdw0);
+                store(i + N, i, mk(0.0, 0.0), rdw0);
+                store(i + N, i + N, mk(P.diag_d * A.tab[2 * N + i], 0.0), rdw0);
+            }
+        }
     }
+    // electromagnetic: c_nv of the tile's 16 pairs (emme_device.hpp: norm_vel = c_nv W; as make_pair_const)
+    __shared__ double s_cnv[4][16];
+    if (NM > 1 && lane < 16) {
+        const int pidx = tile * TILE_PAIRS + lane;
+        double v = 0.0;
+        if (pidx < A.npairs) {
+            const ushort2 ij = A.pairs[pidx];
+            v = (P.qR * (A.tab[ij.x] - A.tab[ij.y])) / P.vt;
+        }
+        s_cnv[wave][lane] = v;
+    }
+    // c_nv^m of pair slot q of this tile (1 for electrostatic fills); m is the column's moment
+    auto moment_factor = [&](int q, int m) -> double {
+        if (NM == 1) return 1.0;
+        const double cv = s_cnv[wave][q];
+        return m == 0 ? 1.0 : (m == 1 ? cv : cv * cv);
+    };
 
     const double inv_scale = 2. / (M_PI / 2.0);
     // (wg / wk) of this lane's rows: as MFMA A operand (row 4 ks + (lane >> 4), ks < 4) and as node lane & 15
-    double grat[4];
+    double grat[GKS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) grat[ks] = gauss_ratio((4 * ks + (lane >> 4)) >> 1);
-    const double grat_node = gauss_ratio(col);
+    for (int ks = 0; ks < GKS; ++ks) grat[ks] = gauss_ratio<PTS>((4 * ks + (lane >> 4)) >> 1);
+    const double grat_node = gauss_ratio<PTS>(col);  // (node slots 16 .. 31 of GK31 are Kronrod-only)
     const int loff = tile_index(lane >> 4, lane & 15);  // this lane's element of an MFMA operand load, k-step 0
     const int eoff = (lane >> 5) * 16 + (lane & 15);    // the same for the phase block: node 2 ks + (rho >> 1)
     const double2 omw = A.omega[b];                     // this lane's column omega
@@ -375,7 +448,7 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
 #endif
     auto defer = [&](int r, int depth, int ccls, unsigned long long path) {
         const unsigned int slot = atomicAdd(A.worklist_count, 1u);
-        A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)(tile * TILE_PAIRS + rho + 4 * r);
+        A.worklist[slot] = ((unsigned long long)b << 32) | (unsigned int)((tile * TILE_PAIRS + rho + 4 * r) * NM + mom);
         A.defer_info[slot] = ((unsigned long long)depth << 56) | ((unsigned long long)ccls << 55) | (path & 0x7fffffffffffffull);
         deferred[r] = true, alive[r] = false;
 #pragma unroll
@@ -435,8 +508,8 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     if (match[r]) defer(r, depth, ccls, path);
                 continue;
             }
-            const double* ablk = ebuf + blk * TILE_BLOCK;
-            const double* bblk = A.btab + ((size_t)cslot * A.nchunks + chunk) * BTAB_BLOCK;
+            const double* ablk = ebuf + blk * TB;
+            const double* bblk = A.btab + ((size_t)cslot * A.nchunks + chunk) * BT;
             const double2* a2 = reinterpret_cast<const double2*>(ablk);
             const double2* b2 = reinterpret_cast<const double2*>(bblk);
             unsigned int colmask = (unsigned int)((need | (need >> 16) | (need >> 32) | (need >> 48)) & 0xffffull);
@@ -453,28 +526,31 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                 // operand loads are issued before the first MFMA (one exposed latency per entry, not four)
                 // operand maps: A[p = lane & 15][k = 4 ks + (lane >> 4)] = a2[tile_index(k, p)], B[k][w] likewise:
                 // both are base + 64 ks + loff in (re, im) pairs -- ONE coalesced 1-KB load each
-                double2 av[8], ev[8];
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) av[ks] = a2[64 * ks + loff], ev[ks] = b2[32 * ks + eoff];
+                for (int h = 0; h < KS / 8; ++h) {  // (GK31: two batches of eight k-steps, the Gauss rule in the first)
+                    double2 av[8], ev[8];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) av[ks] = a2[64 * (8 * h + ks) + loff], ev[ks] = b2[32 * (8 * h + ks) + eoff];
 #ifndef EMME_DENSE_NO_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0);  // (the loads stay ahead of the first MFMA whatever else the scheduler weighs)
+                    __builtin_amdgcn_sched_barrier(0);  // (the loads stay ahead of the first MFMA whatever else the scheduler weighs)
 #endif
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    // (B rows 4 ks + rho belong to node 2 ks + (rho >> 1): row rho even = omega E', odd = E')
-                    const double2 a = av[ks], ep = ev[ks];
-                    const double2 bk = (rho & 1) ? ep : make_double2(fma(omw.x, ep.x, -(omw.y * ep.y)), fma(omw.x, ep.y, omw.y * ep.x));
-                    // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
-                    Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
-                    Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
-                    K2re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, K2re, 0, 0, 0);
-                    K2im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, K2im, 0, 0, 0);
-                    if (ks < 4) {  // G = sum_k (rho_k Q[p][k]) BK[k][w]: the A operand scaled, the same B
-                        const double gx = a.x * grat[ks], gy = a.y * grat[ks];
-                        Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.x, Gre, 0, 0, 0);
-                        Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.y, Gim, 0, 0, 0);
-                        G2re = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, -bk.y, G2re, 0, 0, 0);
-                        G2im = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, bk.x, G2im, 0, 0, 0);
+                    for (int ks = 0; ks < 8; ++ks) {
+                        // (B rows 4 ks + rho belong to node 2 ks + (rho >> 1): row rho even = omega E', odd = E')
+                        const double2 a = av[ks], ep = ev[ks];
+                        const double2 bk = (rho & 1) ? ep : make_double2(fma(omw.x, ep.x, -(omw.y * ep.y)), fma(omw.x, ep.y, omw.y * ep.x));
+                        // (eight independent accumulation chains instead of four: K's a.x and a.y products apart)
+                        Kre = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.x, Kre, 0, 0, 0);
+                        Kim = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bk.y, Kim, 0, 0, 0);
+                        K2re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -bk.y, K2re, 0, 0, 0);
+                        K2im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bk.x, K2im, 0, 0, 0);
+                        if (8 * h + ks < GKS) {  // G = sum_k (rho_k Q[p][k]) BK[k][w]: the A operand scaled, the same B
+                            const double gx = a.x * grat[(8 * h + ks) % GKS], gy = a.y * grat[(8 * h + ks) % GKS];
+                            Gre = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.x, Gre, 0, 0, 0);
+                            Gim = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, bk.y, Gim, 0, 0, 0);
+                            G2re = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, -bk.y, G2re, 0, 0, 0);
+                            G2im = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, bk.x, G2im, 0, 0, 0);
+                        }
                     }
                 }
                 Kre += K2re, Kim += K2im, Gre += G2re, Gim += G2im;
@@ -525,7 +601,6 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     colmask &= colmask - 1;
                     ++n_cols;
                     double mkx = 0.0, mky = 0.0, mgx = 0.0, mgy = 0.0;
-                    const double2 ep = b2[sn * 16 + c];  // E' of the node; BK0 = E', BK1 = omega_c E'
                     // (omega of column c: it lives in lane c; c is wave-uniform, so v_readlane, not a bpermute through LDS)
                     auto lane_value = [&](double v) -> double {
                         const long long bits = __double_as_longlong(v);
@@ -534,8 +609,6 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
                     };
                     const double wcx = lane_value(omw.x), wcy = lane_value(omw.y);
-                    const cd bk0 = mk(ep.x, ep.y);
-                    const cd bk1 = mk(fma(wcx, ep.x, -(wcy * ep.y)), fma(wcx, ep.y, wcy * ep.x));
                     // the four pairs' node products, then ONE reduction per quantity for all four: two halving
                     // exchanges (row_mirror, row_half_mirror: a lane keeps half of what it holds and adds the
                     // partner's copy of it), then two butterfly steps inside the quad -- 5 additions per quantity
@@ -546,15 +619,26 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     const int pmask = (col >= 8 ? 2 : 0) | ((col >> 2) & 1);
                     double pkx[4], pky[4], pgx[4], pgy[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int p = rho + 4 * (r ^ pmask);
-                        const double4 ra = *reinterpret_cast<const double4*>(a2 + tile_index(2 * sn, p));  // (Q1, Q0): 32 bytes
-                        const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);
-                        // fk = q1 bk1 + q0 bk0, one multiplication and three FMAs per component
-                        const cd fk = mk(fma(q1.x, bk1.x, fma(-q1.y, bk1.y, fma(q0.x, bk0.x, -(q0.y * bk0.y)))),
-                                         fma(q1.x, bk1.y, fma(q1.y, bk1.x, fma(q0.x, bk0.y, q0.y * bk0.x))));
-                        const cd fg = grat_node * fk;  // the Gauss rule's term of this node: (wg / wk) times the Kronrod one
-                        pkx[r] = fk.x, pky[r] = fk.y, pgx[r] = fg.x, pgy[r] = fg.y;
+                    for (int h = 0; h < NS / 16; ++h) {  // (GK31: a lane takes node slots col and col + 16)
+                        const int snh = sn + 16 * h;
+                        const double2 ep = b2[snh * 16 + c];  // E' of the node; BK0 = E', BK1 = omega_c E'
+                        const cd bk0 = mk(ep.x, ep.y);
+                        const cd bk1 = mk(fma(wcx, ep.x, -(wcy * ep.y)), fma(wcx, ep.y, wcy * ep.x));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int p = rho + 4 * (r ^ pmask);
+                            const double4 ra = *reinterpret_cast<const double4*>(a2 + tile_index(2 * snh, p));  // (Q1, Q0): 32 bytes
+                            const cd q1 = mk(ra.x, ra.y), q0 = mk(ra.z, ra.w);
+                            // fk = q1 bk1 + q0 bk0, one multiplication and three FMAs per component
+                            const cd fk = mk(fma(q1.x, bk1.x, fma(-q1.y, bk1.y, fma(q0.x, bk0.x, -(q0.y * bk0.y)))),
+                                             fma(q1.x, bk1.y, fma(q1.y, bk1.x, fma(q0.x, bk0.y, q0.y * bk0.x))));
+                            if (h == 0) {
+                                const cd fg = grat_node * fk;  // the Gauss rule's term of this node: (wg / wk) times the Kronrod one
+                                pkx[r] = fk.x, pky[r] = fk.y, pgx[r] = fg.x, pgy[r] = fg.y;
+                            } else {
+                                pkx[r] += fk.x, pky[r] += fk.y;
+                            }
+                        }
                     }
                     auto mv_reduce = [&](const double (&v)[4]) -> double {
                         const double w0 = v[0] + dpp_mov<0x140>(v[3]), w1 = v[1] + dpp_mov<0x140>(v[2]);
@@ -582,7 +666,12 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
                     const unsigned long long mbq = dq == 0 ? mb[0] : dq == 1 ? mb[1] : dq == 2 ? mb[2] : mb[3];
                     int qbad = 0;
                     bool sp = false;
-                    if (decider && ((mbq >> owner) & 1ull)) sp = decide(dq, owner, mkx, mky, mgx, mgy, qbad);
+                    if (decider && ((mbq >> owner) & 1ull)) {
+                        // (column c is wave-uniform, and so is its moment; the decider lane's pair slot is rho + 4 dq)
+                        const double cf = moment_factor(rho + 4 * dq, NM == 1 ? 0 : c % NM);
+                        sp = NM == 1 ? decide(dq, owner, mkx, mky, mgx, mgy, qbad)
+                                     : decide(dq, owner, mkx * cf, mky * cf, mgx * cf, mgy * cf, qbad);
+                    }
                     const unsigned long long sb = __ballot(sp), bb = __ballot(qbad != 0);
                     if (col == c) {
 #pragma unroll
@@ -602,7 +691,14 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (__ballot(match[r]) == 0ull) continue;  // wave-uniform
-                    if (match[r]) split[r] = decide(r, lane, Kre[r], Kim[r], Gre[r], Gim[r], bad);
+                    if (match[r]) {
+                        if (NM == 1) {
+                            split[r] = decide(r, lane, Kre[r], Kim[r], Gre[r], Gim[r], bad);
+                        } else {
+                            const double cf = moment_factor(rho + 4 * r, mom);
+                            split[r] = decide(r, lane, Kre[r] * cf, Kim[r] * cf, Gre[r] * cf, Gim[r] * cf, bad);
+                        }
+                    }
                 }
             }
             if (__ballot(split[0] || split[1] || split[2] || split[3]) != 0ull) {
@@ -670,11 +766,32 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
             const ushort2 ij = A.pairs[pidx];
             const int i = ij.x, j = ij.y;
             const cd sm = mk(s_sumx[wave][r][lane], s_sumy[wave][r][lane]);
-            const cd kap = mk(P.pref * sm.y, -(P.pref * sm.x));  // -i pref sum, Parameters.cpp:182
+            cd kap = mk(P.pref * sm.y, -(P.pref * sm.x));  // -i pref sum, Parameters.cpp:182
             if (kappa_bad(kap)) bad = 1;
-            const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
-            store(i, j, v, rdw);
-            store(j, i, v, rdw);
+            if (NM == 1) {
+                const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
+                store(i, j, v, rdw);
+                store(j, i, v, rdw);
+            } else {
+                // blocks A (m = 0), B and its mirrors (m = 1), D (m = 2): include/solver.h:472-509
+                const double de = A.tab[i] - A.tab[j], dg = A.tab[N + i] - A.tab[N + j];
+                kap = kap + kappa_e(mom, P, de, dg, mk(omw.x, omw.y));
+                if (mom == 0) {
+                    const cd v = (-(pair_weight(i, j, N) * P.dx)) * kap;
+                    store(i, j, v, rdw);
+                    store(j, i, v, rdw);
+                } else if (mom == 1) {
+                    const cd v = P.dx * kap;
+                    store(i, j + N, v, rdw);
+                    store(j, i + N, -v, rdw);
+                    store(i + N, j, -v, rdw);
+                    store(j + N, i, v, rdw);
+                } else {
+                    const cd v = P.dx * kap;
+                    store(i + N, j + N, v, rdw);
+                    store(j + N, i + N, v, rdw);
+                }
+            }
         }
     }
     // interval count of this wave's 16 pairs per omega column: the four row lanes of a column, then the
@@ -716,17 +833,19 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
 
 }  // namespace
 
-size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part) {
+size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part, int gk_points) {
     const CacheGeom c = make_geom(g);
     const int ni = part < 0 ? c.ni_main() : c.ni_sub(part + 1);
     const size_t ntiles = (size_t)((npairs + TILE_PAIRS - 1) / TILE_PAIRS);
-    return ntiles * (size_t)ni * TILE_BLOCK * sizeof(double);
+    return ntiles * (size_t)ni * tile_block_doubles(gk_points) * sizeof(double);
 }
 
-size_t btab_bytes(int nslots, int nchunks) { return (size_t)nslots * nchunks * BTAB_BLOCK * sizeof(double); }
+size_t btab_bytes(int nslots, int nchunks, int gk_points) {
+    return (size_t)nslots * nchunks * btab_block_doubles(gk_points) * sizeof(double);
+}
 
 hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi, void* recs,
-                                   void* ttab, double* scale, hipStream_t stream, unsigned char* tile_poison) {
+                                   void* ttab, double* scale, hipStream_t stream, unsigned char* tile_poison, void* wtab) {
     TiledCacheArgs A;
     A.tile_poison = tile_poison;
     A.P = L.P;
@@ -737,19 +856,25 @@ hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom&
     A.omi = omi;
     A.recs = (double*)recs;
     A.ttab = (double2*)ttab;
+    A.wtab = (double2*)wtab;
     A.scale = scale;
     A.part = part;
     A.first = part < 0 ? 0 : A.geom.base[part + 1];
     A.count = part < 0 ? A.geom.ni_main() : A.geom.ni_sub(part + 1);
     if (A.count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_node_cache_tiled, dim3(256 * 32), dim3(256), 0, stream, A);
+    if (L.gk_points == 15)
+        hipLaunchKernelGGL(k_node_cache_tiled<15>, dim3(256 * 32), dim3(256), 0, stream, A);
+    else
+        hipLaunchKernelGGL(k_node_cache_tiled<31>, dim3(256 * 32), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 
-hipError_t launch_btab(int nslots, const void* const ttab[2], const double* omega, const int* act_idx, int n_act,
-                       const int* wmap, int nchunks, void* btab, hipStream_t stream) {
+hipError_t launch_btab(int gk_points, int nm, int nslots, const void* const ttab[2], const void* const wtab[2],
+                       const double* omega, const int* act_idx, int n_act, const int* wmap, int nchunks, void* btab,
+                       hipStream_t stream) {
     BtabArgs A;
     A.ttab[0] = (const double2*)ttab[0], A.ttab[1] = (const double2*)ttab[1];
+    A.wtab[0] = wtab ? (const double2*)wtab[0] : nullptr, A.wtab[1] = wtab ? (const double2*)wtab[1] : nullptr;
     A.omega = (const double2*)omega;
     A.act_idx = act_idx;
     A.wmap = wmap;
@@ -757,11 +882,16 @@ hipError_t launch_btab(int nslots, const void* const ttab[2], const double* omeg
     A.nchunks = nchunks;
     A.nslots = nslots;
     A.btab = (double*)btab;
-    const long total = (long)nslots * 16 * n_act;
+    const long total = (long)nslots * tile_slots(gk_points) * n_act;
     long blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_btab, dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    if (gk_points == 15 && nm == 1)
+        hipLaunchKernelGGL((k_btab<15, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    else if (gk_points == 31 && nm == 3)
+        hipLaunchKernelGGL((k_btab<31, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    else
+        return hipErrorNotSupported;
     return hipGetLastError();
 }
 
@@ -775,6 +905,7 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.tile_poison[0] = tile_poison ? tile_poison[0] : nullptr;
     A.tile_poison[1] = tile_poison ? tile_poison[1] : nullptr;
     A.P = L.P;
+    A.tab = L.tab;
     A.pairs = (const ushort2*)L.pairs;
     A.npairs = L.npairs;
     A.geom = make_geom(g);
@@ -805,12 +936,18 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.overflow = overflow;
     const int ntiles = (L.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;
+    const int nm = L.P.dim == L.P.N ? 1 : 3;
+    if (L.gk_points == 31 && nm == 3) {  // electromagnetic GK31 (64-entry level lists only; tile-major, XCD-aware order)
+        hipLaunchKernelGGL((k_assemble_dense<1, 31, 3>), dim3((unsigned)((long)((ntg + 7) / 8) * 8 * A.nchunks)), dim3(256), 0, stream, A);
+        return hipGetLastError();
+    }
+    if (L.gk_points != 15 || nm != 1) return hipErrorNotSupported;
     // the first n_wide chunks (omegas whose level lists overflowed last time) through the 128-entry build
     if (n_wide > A.nchunks) n_wide = A.nchunks;
-    if (n_wide > 0) hipLaunchKernelGGL(k_assemble_dense<2>, dim3((unsigned)((long)ntg * n_wide)), dim3(256), 0, stream, A);
+    if (n_wide > 0) hipLaunchKernelGGL((k_assemble_dense<2, 15, 1>), dim3((unsigned)((long)ntg * n_wide)), dim3(256), 0, stream, A);
     if (A.nchunks > n_wide) {
         A.chunk0 = n_wide;
-        hipLaunchKernelGGL(k_assemble_dense<1>, dim3((unsigned)((long)ntg * (A.nchunks - n_wide))), dim3(256), 0, stream, A);
+        hipLaunchKernelGGL((k_assemble_dense<1, 15, 1>), dim3((unsigned)((long)ntg * (A.nchunks - n_wide))), dim3(256), 0, stream, A);
     }
     return hipGetLastError();
 }

@@ -227,6 +227,15 @@ struct AllocTimer {
 
 size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
 
+// Which contexts get the tiled record layout + dense (matrix-core) fill (assemble_dense.hip): electrostatic GK15 and
+// electromagnetic GK31 (the two shapes BASELINE.json's configurations use), on folded records, with the default fill
+// option.  The dense path carries the safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature
+// goal (integration_accuracy) is tighter than 1e-9 keep the exact kernels.
+bool wants_tiled(const emme_params_t& p, bool es, bool folded, int fill) {
+    const bool shape = (es && p.integration_start_points == 15) || (!es && p.integration_start_points == 31);
+    return shape && folded && p.integration_accuracy >= 1e-9 && fill == EMME_FILL_AUTO;
+}
+
 void options_default(emme_options_t& o) {
     o = emme_options_t{};
     o.size = (int)sizeof(emme_options_t);
@@ -539,7 +548,7 @@ int items_per_group_for(const emme_ctx* c, long units) {
 long cache_items(const emme_ctx* c) { return (long)c->npairs * (c->em_shared ? 1 : c->nm); }
 // bytes of one part of the node cache in this context's record layout
 size_t cache_part_bytes(const emme_ctx* c, int gk_points, const NodeCacheGeom& g, int part) {
-    return c->tiled ? node_cache_bytes_tiled(c->npairs, g, part) : node_cache_bytes(gk_points, cache_items(c), g, part);
+    return c->tiled ? node_cache_bytes_tiled(c->npairs, g, part, gk_points) : node_cache_bytes(gk_points, cache_items(c), g, part);
 }
 hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCacheGeom& g, int part, int cls, void* recs) {
     const double omi = cls == 0 ? 1.0 : -1.0;
@@ -550,7 +559,8 @@ hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCach
             const hipError_t e = hipMemsetAsync(c->d_tile_poison[cls], 0, ntiles, c->stream);
             if (e != hipSuccess) return e;
         }
-        hipError_t e = launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream, c->d_tile_poison[cls]);
+        hipError_t e = launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream, c->d_tile_poison[cls],
+                                               c->nm > 1 ? c->d_wtab[cls] : nullptr);
         if (e == hipSuccess && std::getenv("EMME_DEBUG")) {
             const size_t ntiles = ((size_t)c->npairs + 15) / 16;
             std::vector<unsigned char> flags(ntiles);
@@ -606,7 +616,7 @@ bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
     if (c->cache_bytes_used + (double)bytes > budget ||
         pool_alloc(&c->d_recs[cls], bytes, c->device) != hipSuccess ||
         malloc_retry(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
-        (c->em_shared &&
+        ((c->em_shared || (c->tiled && c->nm > 1)) &&
          malloc_retry(&c->d_wtab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess) ||
         (!c->d_scale &&
          malloc_retry((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
@@ -726,7 +736,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     // omegas whose level lists overflowed in their previous fill (root search only): first, a chunk each, through the
     // wide-list build of the dense fill
     int n_wide = 0;
-    if (newton_loop && c->tiled && !c->h_wide.empty()) {
+    if (newton_loop && c->tiled && c->nm == 1 && !c->h_wide.empty()) {
         std::stable_partition(idx.begin(), idx.end(), [&](int b) { return c->h_wide[b] != 0; });
         for (int b : idx) n_wide += c->h_wide[b] != 0;
     }
@@ -816,7 +826,9 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             // tile tasks than the chip holds waves: the widest chunk shrinks until there are at least
             // EMME_DENSE_MIN_TASKS (2000; 8000 while every lane ended with a global atomic -- with the counters
             // summed per workgroup 0 .. 3000 are equal, 44.7 ms of fill per bench search, and 8000 costs 45.8)
-            int dense_cap = gw;
+            // (dense fill: a chunk is 16 COLUMNS -- 16 omegas, or 5 omegas x 3 moments)
+            const int tile_cap = 16 / c->nm;
+            int dense_cap = c->tiled ? tile_cap : gw;
             if (c->tiled) {
                 const long ntiles = (c->npairs + 15) / 16;
                 const long min_tasks = c->opt.dense_min_tasks;
@@ -828,7 +840,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             while (q < idx.size()) {
                 int cap = c->tiled ? dense_cap : gw;
                 while ((!union_walk || c->tiled) && cap > (c->tiled ? 2 : 1) &&
-                       (double)cs[q] * cap > typical * gw * (c->tiled ? dense_ratio : 1.5))
+                       (double)cs[q] * cap > typical * (c->tiled ? tile_cap * dense_ratio : gw * 1.5))
                     cap >>= 1;
                 const int n = (int)std::min<size_t>((size_t)cap, idx.size() - q);
                 ch.push_back((int)q);
@@ -866,7 +878,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             // per (16-pair tile, 16-omega chunk); chunk c = positions 16 c .. of the cost-sorted list
             const int n_int = node_cache_intervals(c->cache_geom);
             const int nch = nchunks;
-            const size_t need = btab_bytes(n_int, nch);
+            const size_t need = btab_bytes(n_int, nch, L.gk_points);
             if (need > c->btab_cap) {
                 if (c->d_btab) (void)hipFree(c->d_btab);
                 c->d_btab = nullptr, c->btab_cap = 0;
@@ -875,8 +887,8 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
             }
             {
                 ScopedSpan s(c, K_OTHER);
-                HIP_TRY(launch_btab(n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_chunks + 2 * nchunks, nchunks,
-                                    c->d_btab, c->stream));
+                HIP_TRY(launch_btab(L.gk_points, c->nm, n_int, c->d_ttab, c->d_wtab, d_omega, c->d_actidx, n_lane,
+                                    c->d_chunks + 2 * nchunks, nchunks, c->d_btab, c->stream));
             }
             {
                 ScopedSpan s(c, K_ASM);
@@ -895,7 +907,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                 HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
                                               c->d_chunks, nchunks, c->d_rounds, c->stream, c->d_tile_poison,
-                                              c->opt.dense_wide ? nchunks : n_wide, newton_loop ? c->d_overflow : nullptr));
+                                              (c->opt.dense_wide && c->nm == 1) ? nchunks : n_wide, newton_loop ? c->d_overflow : nullptr));
                 if (stamps) {
                     HIP_TRY(hipEventRecord(e1, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -950,9 +962,12 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         }
         if (n_lane) {
             ScopedSpan s(c, K_DEFER);
-            HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, &c->cache_geom, c->d_recs,
+            // (tiled electromagnetic contexts: the cooperative kernel does not read 32-slot tile blocks -- the few
+            // integrals that leave the cache are evaluated from scratch)
+            const bool coop_cached = !(c->tiled && c->nm > 1);
+            HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, coop_cached ? &c->cache_geom : nullptr, c->d_recs,
                                          c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream,
-                                         c->tiled, c->d_tile_poison));
+                                         c->tiled && coop_cached, c->d_tile_poison));
         }
         if (std::getenv("EMME_DEBUG")) {
             unsigned int cnt = 0;
@@ -1062,8 +1077,7 @@ int emme_ctx_create_ex(const emme_params_t* p, int device, const emme_options_t*
     // (assemble_dense.hip) instead of the union walk (EMME_DENSE=0 restores that).  It
     // carries the safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature goal
     // (integration_accuracy) is tighter than 1e-9 keep the exact union kernel.
-    c->tiled = es && p->integration_start_points == 15 && c->folded && p->integration_accuracy >= 1e-9 &&
-               o.fill == EMME_FILL_AUTO;
+    c->tiled = wants_tiled(*p, es, c->folded, o.fill);
 
     DevParams& P = c->P;
     std::vector<double> tab(3 * (size_t)N);
@@ -1164,8 +1178,7 @@ int emme_ctx_set_options(emme_ctx_t* c, const emme_options_t* opt) {
         const bool es = c->nm == 1;
         c->em_shared = !es && opt->em_shared != 0;
         c->folded = opt->phase_table != 0;
-        c->tiled = es && c->p.integration_start_points == 15 && c->folded && c->p.integration_accuracy >= 1e-9 &&
-                   opt->fill == EMME_FILL_AUTO;
+        c->tiled = wants_tiled(c->p, es, c->folded, opt->fill);
     }
     if (opt->node_cache_gb > 0.0 && c->cache_depth == -2 && !c->d_recs[0] && !c->d_recs[1])
         c->cache_depth = -1;  // a budget after "no cache": decide again

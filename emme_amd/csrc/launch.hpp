@@ -92,19 +92,21 @@ hipError_t launch_assemble_list(const AssembleLaunch& L, const unsigned long lon
                                 const void* const ttab[2], const void* const wtab[2], bool folded,
                                 hipStream_t stream, bool tiled = false, const unsigned char* const tile_poison[2] = nullptr);
 
-// ---- dense (matrix-core) fill of electrostatic GK15 contexts: assemble_dense.hip ------------------
-// tiled record layout: see node_cache.hpp
-size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part);
-// tile_poison [ntiles] (device, zeroed once per contour class): set to 1 for every tile that gets a poisoned block
+// ---- dense (matrix-core) fill: assemble_dense.hip (electrostatic GK15; electromagnetic GK31) ------
+// tiled record layout: see node_cache.hpp (gk_points 15: 8 KB per (tile, interval); 31: 16 KB)
+size_t node_cache_bytes_tiled(long npairs, const NodeCacheGeom& g, int part, int gk_points = 15);
+// tile_poison [ntiles] (device, zeroed once per contour class): set to 1 for every tile that gets a poisoned block;
+// wtab (electromagnetic contexts): the moment factor W per (interval, node lane), written beside ttab
 hipError_t launch_node_cache_tiled(const AssembleLaunch& L, const NodeCacheGeom& g, int part, double omi,
                                    void* recs, void* ttab, double* scale, hipStream_t stream,
-                                   unsigned char* tile_poison = nullptr);
-// weighted phase tables of one launch: btab_bytes(cached intervals, ceil(n_act / 16))
-size_t btab_bytes(int nslots, int nchunks);
-// wmap[position in the omega list] = chunk << 8 | column of that omega
-hipError_t launch_btab(int nslots, const void* const ttab[2], const double* omega, const int* act_idx,
-                       int n_act, const int* wmap, int nchunks, void* btab, hipStream_t stream);
-// act_idx: the launch's omegas, cost-sorted; chunks: int2 (first position, size <= 16) per chunk.
+                                   unsigned char* tile_poison = nullptr, void* wtab = nullptr);
+// weighted phase tables of one launch: btab_bytes(cached intervals, chunks of the launch)
+size_t btab_bytes(int nslots, int nchunks, int gk_points = 15);
+// wmap[position in the omega list] = chunk << 8 | position of that omega in its chunk (its first column / nm)
+hipError_t launch_btab(int gk_points, int nm, int nslots, const void* const ttab[2], const void* const wtab[2],
+                       const double* omega, const int* act_idx, int n_act, const int* wmap, int nchunks, void* btab,
+                       hipStream_t stream);
+// act_idx: the launch's omegas, cost-sorted; chunks: int2 (first position, size <= 16 / nm) per chunk.
 // stats (nullable): counters (dense rounds, vector rounds, vector columns, tile tasks, ...)
 hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g, const void* const recs[2],
                                  const void* const recs_ext[2][NODE_CACHE_MAX_SUB - 1], const double* scale,

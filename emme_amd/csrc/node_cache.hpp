@@ -76,14 +76,23 @@ struct CacheGeom {
 // complex GEMMs against per-launch tables of weighted phases (k_btab).  Re A0 is not kept: neither the
 // dense fill nor the cooperative kernel applies the safe_exp clamp to tiled records (the clamped tails are
 // <= 4e-14 absolute, assemble_dense.hip), and records that are not finite are zeroed when they are built.
+// GK31 (round 3: the electromagnetic dense fill) has 32 node slots -- 15 Gauss nodes first, the 16 Kronrod-only
+// ones behind them, slot 31 padding -- in the same [sn][p][which] order: 16 KB per (tile, interval).
 constexpr int TILE_PAIRS = 16;
-constexpr int TILE_BLOCK = 2 * 32 * 16;  // doubles: 8 KB per (tile, interval)
-__host__ __device__ inline int slotnode_of_lane(int lane) {
-    if (lane >= 15) return 15;
-    const int q = lane < 8 ? lane : lane - 7, neg = lane >= 8 ? 1 : 0;
+constexpr int TILE_BLOCK = 2 * 32 * 16;  // doubles: 8 KB per (tile, interval), GK15
+__host__ __device__ constexpr int tile_slots(int pts) { return pts == 15 ? 16 : 32; }
+__host__ __device__ constexpr int tile_block_doubles(int pts) { return 4 * tile_slots(pts) * 16; }
+__host__ __device__ constexpr int btab_block_doubles(int pts) { return 2 * tile_slots(pts) * 16; }
+// node slot of lane r of a lane group (gk_lane<PTS>(r): centre, +x_1 .. +x_{H-1}, -x_1 .. -x_{H-1}, padding)
+template <int PTS>
+__host__ __device__ inline int slotnode_of_lane_t(int lane) {
+    constexpr int H = (PTS + 1) / 2;
+    if (lane >= PTS) return tile_slots(PTS) - 1;
+    const int q = lane < H ? lane : lane - (H - 1), neg = lane >= H ? 1 : 0;
     if (q == 0) return 0;
-    return (q & 1) ? 6 + q + neg : q - 1 + neg;
+    return (q & 1) ? (H - 1) + (q - 1) + neg : q - 1 + neg;
 }
+__host__ __device__ inline int slotnode_of_lane(int lane) { return slotnode_of_lane_t<15>(lane); }
 // per-launch table of weighted phases, one block per (interval slot, omega chunk of 16):
 //     E'[sn][column omega] = wk_sn exp(T_sn omega)   as (re, im) pairs, 4 KB.
 // The GEMM's B rows of node sn are 2 sn: omega E' and 2 sn + 1: E'; the fill forms the first from the second
