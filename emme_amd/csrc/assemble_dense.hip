@@ -245,6 +245,8 @@ struct DenseArgs {
     int dense_min_cols;         // columns that must need an interval for the MFMA path
     int skip_lost;              // columns whose matrix is already flagged (status) are left alone
     int chunk0;                 // first chunk of this launch
+    int nch_launch;             // chunks this launch serves (chunk0 .. chunk0 + nch_launch - 1)
+    int tile_major;             // task order: the chunks of a tile group back to back on one XCD (else chunk-major)
     unsigned int* overflow;     // [nbatch] integrals handed over because a level list was full (null: not counted)
 };
 
@@ -300,12 +302,12 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     const int ntg = (ntiles + 3) / 4;  // tile groups: 4 tiles (one per wave) per workgroup
     int chunk = A.chunk0 + blockIdx.x / ntg;
     int tile = (blockIdx.x - (chunk - A.chunk0) * ntg) * 4 + wave;
-    if (NM > 1) {
+    if (NM > 1 || A.tile_major) {
         // Electromagnetic launches have 3.2 times the chunks (5 omegas each) and 16-KB record blocks: in chunk-major
         // order every chunk fetched every block of its tiles from HBM again (26 chunks x 390 MB per launch).  Here
         // the chunks of a tile group run back to back ON ONE XCD (workgroup ids go round the eight XCDs), whose L2
         // then serves the tile's blocks to all but the first.
-        const int nch = A.nchunks - A.chunk0;
+        const int nch = A.nch_launch;
         const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
         const int tg = (k / nch) * 8 + xcd;
         chunk = A.chunk0 + k % nch;
@@ -933,6 +935,8 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     A.dense_min_cols = L.dense_min_cols;
     A.skip_lost = L.skip_lost;
     A.chunk0 = 0;
+    A.nch_launch = nchunks;
+    A.tile_major = 0;
     A.overflow = overflow;
     const int ntiles = (L.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;
@@ -944,10 +948,21 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     if (L.gk_points != 15 || nm != 1) return hipErrorNotSupported;
     // the first n_wide chunks (omegas whose level lists overflowed last time) through the 128-entry build
     if (n_wide > A.nchunks) n_wide = A.nchunks;
-    if (n_wide > 0) hipLaunchKernelGGL((k_assemble_dense<2, 15, 1>), dim3((unsigned)((long)ntg * n_wide)), dim3(256), 0, stream, A);
+    // (experiment, EMME_EXP_TILE_MAJOR = n: the electromagnetic task order for electrostatic launches of >= n chunks
+    // too.  For ALL launches it is 57 against 35 ms per bench search: the late launches end on their expensive chunk)
+    static const int tm_min = std::getenv("EMME_EXP_TILE_MAJOR") ? std::atoi(std::getenv("EMME_EXP_TILE_MAJOR")) : 0;
+    A.tile_major = tm_min > 0 && A.nchunks - n_wide >= tm_min;
+    const long ntg_l = A.tile_major ? (long)((ntg + 7) / 8) * 8 : ntg;
+    if (n_wide > 0) {
+        const int tm = A.tile_major;
+        A.nch_launch = n_wide, A.tile_major = 0;
+        hipLaunchKernelGGL((k_assemble_dense<2, 15, 1>), dim3((unsigned)((long)ntg * n_wide)), dim3(256), 0, stream, A);
+        A.tile_major = tm;
+    }
     if (A.nchunks > n_wide) {
         A.chunk0 = n_wide;
-        hipLaunchKernelGGL((k_assemble_dense<1, 15, 1>), dim3((unsigned)((long)ntg * (A.nchunks - n_wide))), dim3(256), 0, stream, A);
+        A.nch_launch = A.nchunks - n_wide;
+        hipLaunchKernelGGL((k_assemble_dense<1, 15, 1>), dim3((unsigned)(ntg_l * (A.nchunks - n_wide))), dim3(256), 0, stream, A);
     }
     return hipGetLastError();
 }

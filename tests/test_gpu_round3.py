@@ -73,6 +73,50 @@ def test_damped_omegas_full_size_match_reference_checksums(emme):
     print(f"damped omegas: worst entry error / tolerance = {worst:.3g}")
 
 
+# ---- 1b. the electromagnetic dense fill, full size ------------------------------------------------------------
+def test_em_dense_fill_full_size_matches_reference_checksums(emme):
+    """BASELINE configs[3] (stellarator, electromagnetic, GK31, N = 256, dim 512) at nine omegas taken verbatim from
+    the reference's own K = 8 chains (cfg4_k8_n256.npz), six of them at Im omega <= 0 where the three moments' trees
+    are 5-11 intervals deep per integral: ONE batch on a default context -> the electromagnetic dense fill
+    (k_assemble_dense<1, 31, 3>: three moments as columns of a 16 x 16 x 64 GEMM, tiled GK31 records).
+    Pinned against oracle/_ref checksums (make_golden_cfg4_damped.py): Frobenius norm, sum, the 512 row sums and 40
+    entries from all four blocks within max(1e-12 max|M|, 10 x the reference's own spread under omega (1 + 1e-13));
+    the total interval count of every matrix against the C restatement's (last-bit differences from _ref on these
+    matrices, `oracle_bits_equal` = 0: the counts are the restatement's); and against the independent-lane kernel
+    (k_assemble_cached_em) entry by entry with equal counts."""
+    from oracle.binding import example_stellarator
+    z = np.load(os.path.join(G, "cfg4_damped.npz"))
+    assert z["done"].all() and (z["nonfinite"] == 0).all()
+    ws, eij = z["omegas"], z["eij"]
+    assert (ws.imag <= 0).sum() >= 5
+    d = example_stellarator(npoints=256)
+    with _ctx(emme, d) as ctx:
+        M, iv = ctx.assemble(ws, want_intervals=True)
+        M2, iv2 = ctx.assemble(ws, want_intervals=True)
+        assert ctx.fill_kernel_symbol() == "k_assemble_dense<1, 31, 3>"
+    with _ctx(emme, d, fill=emme.FILL_LANES) as ctx:
+        Ml, ivl = ctx.assemble(ws, want_intervals=True)
+        assert ctx.fill_kernel_symbol().startswith("k_assemble_cached_em<31")
+    assert np.array_equal(iv, iv2) and np.array_equal(M.view(np.float64), M2.view(np.float64))
+    assert np.array_equal(iv, ivl)
+    worst = 0.0
+    for k, w in enumerate(ws):
+        assert iv[k] == z["intervals"][k], (w, iv[k], z["intervals"][k])
+        mx = z["maxabs"][k]
+        tol = max(1e-12 * mx, 10.0 * z["spread_max"][k])
+        e_ent = np.abs(M[k][eij[:, 0], eij[:, 1]] - z["entries"][k]).max()
+        e_row = np.abs(M[k].sum(axis=1) - z["rowsum"][k]).max()
+        e_fro = abs(np.sqrt((np.abs(M[k]) ** 2).sum()) - z["fro"][k])
+        e_sum = abs(M[k].sum() - z["sum"][k])
+        assert e_ent <= tol, (w, e_ent, tol)
+        assert e_row <= 16 * tol and e_fro <= 16 * tol and e_sum <= 512 * tol, (w, e_row, e_fro, e_sum, tol)
+        assert np.abs(M[k] - Ml[k]).max() <= 1e-13 * mx
+        assert np.abs(M[k] - M[k].T).max() == 0.0  # include/solver.h:472-509: every block is written with its mirror
+        worst = max(worst, e_ent / tol)
+    print(f"EM dense fill, 9 omegas at dim 512: worst entry error / tolerance = {worst:.3g}; intervals per integral "
+          f"{iv.min() / 97920:.2f} .. {iv.max() / 97920:.2f}")
+
+
 # ---- 2. the dense fill's unclamped tails, entry by entry ----------------------------------------------------
 def test_dense_fill_clamped_tails_entry_by_entry(emme, oracle):
     """safe_exp (src/Parameters.cpp:167-173) zeroes a node when Re(A0 + T omega) < -40.  The dense fill cannot
