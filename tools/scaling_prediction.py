@@ -52,8 +52,14 @@ if "--all" in sys.argv:
             ms.append(round(t, 2)), pts.append(p)
     out["config4_shares"] = {"share_ms": ms, "share_omega_points": pts, "max_over_mean": round(max(ms) / np.mean(ms), 4)}
     ms, pts = [], []
-    for share in range(8):
+    for share in [0] + list(range(8)):  # (share 0 once untimed first: the process's buffer pool changes size class here)
         krs, g = bench.sweep_cfg5(share)
+        if len(ms) == 0 and share == 0 and not pts and not globals().get("_warmed"):
+            _warmed = True
+            for kr in krs:
+                with emme_amd.Context(emme_amd.params_from_dict(bench.workload_dict(512, k_rho=float(kr)))) as ctx:
+                    ctx.solve_roots(g)
+            continue
         t0 = time.perf_counter()
         p = 0
         for kr in krs:
