@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256, EMME_DENSE_MIN_WAVES) void k_assemble_dense(De
     const int cls = -copysign(1.0, A.omega[b].x) > 0.0 ? 0 : 1;
     // (everything the stores need is fetched again after the walk: nothing of it stays live in the loop)
     auto store = [&](int r, int c, cd v, cd rdw) {
+#ifdef EMME_EXP_UPPER_ONLY  // timing experiment: what the mirrored half of the stores costs
+        if (r > c) return;
+#endif
         const size_t idx = (size_t)b * dim * dim + (size_t)r * dim + c;
         A.M[idx] = make_double2(v.x, v.y);
         if (A.Mold) {

@@ -1583,8 +1583,8 @@ int emme_solve_roots(emme_ctx_t* c, const double* guesses, int n, double tol, in
             // the secant M' of the step just taken, then this step's matrix becomes the "previous" one (and the
             // LU's work copy): one pass, for the chains still iterating only
             ScopedSpan s(c, K_OTHER);
-            HIP_TRY(launch_secant_copy(c->dim, n, c->d_M, c->d_Mold, fused_copy ? c->d_work : nullptr, c->d_Mp,
-                                       c->d_domega, c->d_active, c->stream));
+            HIP_TRY(launch_secant_copy_sym(c->dim, n, c->d_M, c->d_Mold, fused_copy ? c->d_work : nullptr, c->d_Mp,
+                                           c->d_domega, c->d_active, c->stream));
         }
         {
             ScopedSpan s(c, K_LIN);

@@ -129,6 +129,11 @@ hipError_t launch_copy_active(int n, int nbatch, const double* src, double* dst1
 hipError_t launch_secant_copy(int n, int nbatch, const double* M, double* Mold, double* work, double* Mp,
                               const double* domega, const int* active, hipStream_t stream);
 
+// the same for matrices that are symmetric bit for bit (every fill kernel writes an entry with its mirror): reads the
+// upper triangles only; Mold is afterwards valid in its upper triangle only
+hipError_t launch_secant_copy_sym(int n, int nbatch, const double* M, double* Mold, double* work, double* Mp,
+                                  const double* domega, const int* active, hipStream_t stream);
+
 // Blocked version (linstep_blocked.hip): whole L21 panel in LDS for n <= ~560, in chunks up to 1024.
 // nwg workgroups per matrix (1: one does everything; > 1: one factors A, the others carry B's
 // columns; `items` = device list of the nitems matrices to work on, null for all of them);

@@ -285,7 +285,70 @@ __global__ __launch_bounds__(256) void k_secant_copy(long elems, const double2* 
     }
 }
 
+// The same pass on SYMMETRIC matrices (include/solver.h:453, 472-509: every entry is written with its mirror, so M and
+// M_old are symmetric bit for bit): only the tiles on and above the diagonal of M and M_old are read, the secant and the
+// work copy are written with their mirror images (transposed through LDS, both coalesced), and M_old is kept in its
+// upper triangle only (nothing else reads it).  2 x 1/2 matrices in, 2 1/2 out instead of 2 in, 3 out.
+constexpr int ST = 32;  // tile edge
+__global__ __launch_bounds__(256) void k_secant_copy_sym(int n, const double2* M, double2* Mold, double2* work,
+                                                         double2* Mp, const double2* domega, const int* active) {
+    const int b = blockIdx.y;
+    if (active && active[b] == 0) return;
+    __shared__ double2 s_v[ST][ST + 1], s_d[ST][ST + 1];
+    // blockIdx.x -> tile (I, J), I <= J, of the nt x nt tile grid: row I holds nt - I tiles
+    const int nt = (n + ST - 1) / ST;
+    int I = 0, rem = blockIdx.x;
+    while (rem >= nt - I) rem -= nt - I, ++I;
+    const int J = I + rem;
+    const cd rdw = rcp(mk(domega[b].x, domega[b].y));
+    const size_t base = (size_t)b * n * n;
+    const int tx = threadIdx.x & (ST - 1), ty = threadIdx.x / ST;  // 32 x 8 threads, 4 rows each
+    for (int rr = ty; rr < ST; rr += 256 / ST) {
+        const int r = I * ST + rr, c = J * ST + tx;
+        double2 v = make_double2(0.0, 0.0), d2 = v;
+        if (r < n && c < n && (I != J || rr <= tx)) {
+            const size_t idx = base + (size_t)r * n + c;
+            v = M[idx];
+            const double2 vo = Mold[idx];
+            const cd d = (mk(v.x, v.y) - mk(vo.x, vo.y)) * rdw;
+            d2 = make_double2(d.x, d.y);
+            Mold[idx] = v;
+        }
+        s_v[rr][tx] = v, s_d[rr][tx] = d2;
+    }
+    __syncthreads();
+    // tile (I, J) itself (a diagonal tile takes its lower half from the transposed upper half) ...
+    for (int rr = ty; rr < ST; rr += 256 / ST) {
+        const int r = I * ST + rr, c = J * ST + tx;
+        if (r < n && c < n) {
+            const bool lower = I == J && rr > tx;
+            const size_t idx = base + (size_t)r * n + c;
+            Mp[idx] = lower ? s_d[tx][rr] : s_d[rr][tx];
+            if (work) work[idx] = lower ? s_v[tx][rr] : s_v[rr][tx];
+        }
+    }
+    // ... and its mirror image (J, I)
+    if (I != J) {
+        for (int rr = ty; rr < ST; rr += 256 / ST) {
+            const int r = J * ST + rr, c = I * ST + tx;
+            if (r < n && c < n) {
+                const size_t idx = base + (size_t)r * n + c;
+                Mp[idx] = s_d[tx][rr];
+                if (work) work[idx] = s_v[tx][rr];
+            }
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_secant_copy_sym(int n, int nbatch, const double* M, double* Mold, double* work, double* Mp,
+                                  const double* domega, const int* active, hipStream_t stream) {
+    const int nt = (n + ST - 1) / ST;
+    hipLaunchKernelGGL(k_secant_copy_sym, dim3((unsigned)(nt * (nt + 1) / 2), nbatch), dim3(256), 0, stream, n,
+                       (const double2*)M, (double2*)Mold, (double2*)work, (double2*)Mp, (const double2*)domega, active);
+    return hipGetLastError();
+}
 
 hipError_t launch_secant_copy(int n, int nbatch, const double* M, double* Mold, double* work, double* Mp,
                               const double* domega, const int* active, hipStream_t stream) {

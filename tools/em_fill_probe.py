@@ -14,7 +14,11 @@ res = {}
 for name, opts in (("default", {}), ("lanes", dict(fill=emme_amd.FILL_LANES))):
     ctx = emme_amd.Context(p, **opts)
     w = g
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and sys.argv[2] == "damped":
+        # 128 omegas around the reference's own step-7 iterate of tests/golden/cfg4_k8_n256.npz, chain 0 (no root search here)
+        z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cfg4_k8_n256.npz"))
+        w = z["iterates"][0, 7] + (g - g.mean()) * 0.5
+    elif len(sys.argv) > 2:
         _, _, _, its = ctx.solve_roots(g, tol=0.0, step_limit=7, want_iterates=True)
         w = its[:, int(sys.argv[2])]
         print("omega[0]", w[0], "spread", np.abs(w - w.mean()).max())
