@@ -3,21 +3,7 @@
 // stand where the reference has EigenSolver's constructor / matrixAssembler /
 // newtonTraceSecantIteration (include/solver.h:396-415, 417-515, 113-160) and the
 // solve_once_eigen loop (src/main.cpp:19-80).
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/emme_hip.h"
-#include "launch.hpp"
+#include "ctx.hpp"
 
 namespace emme {
 
@@ -25,15 +11,6 @@ static thread_local std::string g_error;
 void set_error(const std::string& msg) { g_error = msg; }
 
 namespace {
-
-#define HIP_TRY(expr)                                                                  \
-    do {                                                                               \
-        hipError_t e_ = (expr);                                                        \
-        if (e_ != hipSuccess) {                                                        \
-            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));             \
-            return e_ == hipErrorOutOfMemory ? EMME_ENOMEM : EMME_EDEVICE;             \
-        }                                                                              \
-    } while (0)
 
 bool is_device_ptr(const void* p) {
     if (!p) return false;
@@ -46,184 +23,26 @@ bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice;
 }
 
-enum Kind { K_ASM = 0, K_LIN = 1, K_OTHER = 2, K_DEFER = 3, K_CACHE = 4, K_NULL = 5 };
-
 }  // namespace
 }  // namespace emme
 
 using namespace emme;
 
-struct emme_ctx {
-    emme_params_t p;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    DevParams P;
-    int N = 0, dim = 0, nm = 1, npairs = 0;
-    double* d_tab = nullptr;
-    ushort2* d_pairs = nullptr;
-    // batch scratch
-    int cap = 0;
-    double *d_omega = nullptr, *d_domega = nullptr, *d_tr = nullptr;
-    int *d_active = nullptr, *d_iters = nullptr, *d_info = nullptr, *d_status = nullptr;
-    unsigned long long* d_intervals = nullptr;
-    unsigned long long* d_rounds = nullptr;  // diagnostic counter of the omega-lane kernel
-    int* d_actidx = nullptr;   // compacted list of batch items for the omega-lane kernel
-    int* d_chunks = nullptr;   // (first, size) of every omega chunk of the cached kernel
-    std::vector<int> h_chunks;
-    std::vector<int> h_actidx; // its host image (kept alive across the async upload)
-    int last_fill_mode = -1;   // kernel family of the last fill: 0 nodes, 1 omega-lane, 2 cached
-    emme_options_t opt{};      // per-context options (emme_options_t; environment overrides applied at creation)
-    // HBM cache of omega-independent node records, per contour class (omi = +1, -1)
-    int cache_depth = -1;      // -1: not decided yet, -2: disabled / does not fit, else dfull
-    NodeCacheGeom cache_geom{};
-    int cache_max_intervals = 0;  // capacity of the T / scale tables
-    void* d_recs[2] = {nullptr, nullptr};      // main part per contour class
-    size_t recs_bytes[2] = {0, 0};
-    size_t recs_ext_bytes[2][NODE_CACHE_MAX_SUB - 1] = {};
-    void* d_recs_ext[2][NODE_CACHE_MAX_SUB - 1] = {};  // run-time subtrees per class
-    void* d_ttab[2] = {nullptr, nullptr};      // T table per class
-    void* d_wtab[2] = {nullptr, nullptr};      // moment-factor table per class (shared EM layout)
-    unsigned char* d_tile_poison[2] = {nullptr, nullptr};  // tiled layout: tiles that hold a poisoned block, per class
-    bool em_shared = false;    // nm == 3: one record per (pair, interval, node), three moments per lane
-    bool folded = true;        // records carry exp(A0); exp(T omega) comes from a per-launch phase table
-    bool tiled = false;        // electrostatic GK15: tiled record layout + dense (matrix-core) fill
-    void* d_btab = nullptr;    // weighted phase tables of the current launch (dense fill)
-    size_t btab_cap = 0;
-    void* d_etab = nullptr;    // phase table of the current launch
-    size_t etab_bytes = 0;
-    int* h_lu_items = nullptr;     // blocked LU: the live matrices of the launch (pinned host / device)
-    int* d_lu_items = nullptr;
-    int lu_items_cap = 0;
-    void* d_lu_scratch = nullptr;  // blocked LU: diagonal of X, hand-over flags, row-map snapshots
-    size_t lu_scratch_bytes = 0;
-    int n_cu = 256;                // compute units of the device
-    int last_lu_nwg = 1;           // workgroups per matrix of the last LU launch
-    bool lu_one_wg = false;        // a hand-over of the multi-workgroup LU timed out once: never again
-    int* p_act = nullptr;          // pinned host copies of d_active / d_intervals / omega / the deferred
-    unsigned long long* p_iv = nullptr;  // count, WRITTEN BY KERNELS (k_retire, k_newton_update): the
-    double* p_w = nullptr;         // Newton loop reads them after its one synchronisation per step
-    unsigned int* p_deferred = nullptr;
-    unsigned int* d_overflow = nullptr;  // per item: integrals that left the dense fill because a level list was full
-    unsigned int* p_overflow = nullptr;  // ... published by k_retire
-    std::vector<unsigned char> h_wide;   // items whose chunks take the 128-entry build of the dense fill (root search)
-    int p_cap = 0;
-    bool pub_valid = false;        // last_deferred holds the previous fill's count (from p_deferred)
-    int* p_lists = nullptr;        // pinned staging of the per-launch lists (omega order | chunks), two
-    int p_lists_cap = 0;           // slots used in turn; k_stage_ints moves a slot to device memory
-    unsigned int p_lists_turn = 0;
-    unsigned int lu_items_turn = 0;
-    bool ext_failed = false;
-    unsigned long long* d_defer_info = nullptr;  // missing interval of every deferred integral
-    double cache_bytes_used = 0.0;
-    unsigned int last_deferred = 0;            // integrals the previous cached fill deferred
-    double* d_scale = nullptr;  // half-widths of the cached intervals
-    unsigned long long* d_worklist = nullptr;  // integrals deferred to the cooperative kernel
-    unsigned int* d_worklist_count = nullptr;
-    size_t worklist_cap = 0;
-    int mat_cap = 0;  // matrices per set
-    double *d_M = nullptr, *d_Mold = nullptr, *d_Mp = nullptr, *d_work = nullptr;
-    double* d_iterates = nullptr;
-    size_t iterates_cap = 0;
-    int last_n = 0;
-    // profiling
-    bool prof = false;
-    emme_profile_t acc{};
-    struct Span {
-        int kind;
-        hipEvent_t a, b;
-    };
-    std::vector<Span> spans;
-    std::vector<hipEvent_t> free_events;
-};
+namespace emme {
+
+hipEvent_t get_event(emme_ctx* c) {
+    if (!c->free_events.empty()) {
+        hipEvent_t e = c->free_events.back();
+        c->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace emme
 
 namespace {
-
-// Process-wide pool of the big node-cache buffers.  Allocating ~150 GB takes seconds, far longer
-// than filling it, and a parameter sweep creates one context per parameter set: buffers of a
-// destroyed context are kept and handed to the next one (the records are recomputed anyway).
-struct PoolEntry {
-    void* ptr;
-    size_t bytes;
-    int device;
-};
-std::mutex g_pool_mu;
-std::vector<PoolEntry> g_pool;
-
-void pool_release_all() {
-    std::lock_guard<std::mutex> g(g_pool_mu);
-    for (auto& e : g_pool) {
-        (void)hipSetDevice(e.device);
-        (void)hipFree(e.ptr);
-    }
-    g_pool.clear();
-}
-
-hipError_t pool_alloc(void** out, size_t bytes, int device) {
-    {
-        std::lock_guard<std::mutex> g(g_pool_mu);
-        int best = -1;
-        for (int k = 0; k < (int)g_pool.size(); ++k)
-            if (g_pool[k].device == device && g_pool[k].bytes >= bytes && g_pool[k].bytes <= bytes + bytes / 4 &&
-                (best < 0 || g_pool[k].bytes < g_pool[best].bytes))
-                best = k;
-        if (best >= 0) {
-            *out = g_pool[best].ptr;
-            g_pool.erase(g_pool.begin() + best);
-            return hipSuccess;
-        }
-    }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {  // give the pooled memory back to the driver and try once more
-        (void)hipGetLastError();
-        pool_release_all();
-        e = hipMalloc(out, bytes);
-    }
-    return e;
-}
-
-// hipMalloc that gives pooled cache buffers back to the driver before reporting out-of-memory
-hipError_t malloc_retry(void** out, size_t bytes) {
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        pool_release_all();
-        e = hipMalloc(out, bytes);
-    }
-    return e;
-}
-
-void pool_free(void* p, size_t bytes, int device) {
-    if (!p) return;
-    std::lock_guard<std::mutex> g(g_pool_mu);
-    g_pool.push_back({p, bytes, device});
-    // keep at most ~one large context's worth; evict the oldest buffers beyond that
-    size_t total = 0;
-    for (const auto& e : g_pool) total += e.bytes;
-    while (total > (size_t)200e9 && !g_pool.empty()) {
-        (void)hipSetDevice(g_pool.front().device);
-        (void)hipFree(g_pool.front().ptr);
-        total -= g_pool.front().bytes;
-        g_pool.erase(g_pool.begin());
-    }
-    (void)hipSetDevice(device);
-}
-
-// host wall time of the cache allocations (hipMalloc of tens of GB: the cold cost of a context)
-struct AllocTimer {
-    emme_ctx* c;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    bool running = true;
-    explicit AllocTimer(emme_ctx* ctx) : c(ctx) {}
-    void stop() {
-        if (running) {
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            c->acc.cache_alloc_ms += ms;
-            if (std::getenv("EMME_DEBUG")) fprintf(stderr, "[emme] node cache: allocation took %.1f ms\n", ms);
-        }
-        running = false;
-    }
-    ~AllocTimer() { stop(); }
-};
 
 size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
 
@@ -311,39 +130,6 @@ int options_check(const emme_options_t* o) {
     }
     return EMME_OK;
 }
-
-hipEvent_t get_event(emme_ctx* c) {
-    if (!c->free_events.empty()) {
-        hipEvent_t e = c->free_events.back();
-        c->free_events.pop_back();
-        return e;
-    }
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    return e;
-}
-
-struct ScopedSpan {
-    emme_ctx* c;
-    int kind;
-    hipStream_t st;
-    hipEvent_t a = nullptr, b = nullptr;
-    ScopedSpan(emme_ctx* ctx, int k, hipStream_t on = nullptr, bool use_on = false)
-        : c(ctx), kind(k), st(use_on ? on : ctx->stream) {
-        if (c->prof) {
-            a = get_event(c);
-            b = get_event(c);
-            if (a) (void)hipEventRecord(a, st);
-        }
-    }
-    ~ScopedSpan() {
-        if (c->prof && a && b) {
-            (void)hipEventRecord(b, st);
-            c->spans.push_back({kind, a, b});
-        }
-    }
-};
-
 int drain_spans(emme_ctx* c) {
     for (auto& s : c->spans) {
         HIP_TRY(hipEventSynchronize(s.b));
@@ -532,479 +318,8 @@ int check_method(const emme_ctx* c, int method) {
     return EMME_OK;
 }
 
-int items_per_group_for(const emme_ctx* c, long units) {
-    // enough lane groups to give every SIMD several waves, but a few integrals per group
-    // when the batch is large so the start-up cost (table staging) is amortised
-    const int gw = c->p.integration_start_points == 15 ? 16 : 32;
-    const long total = (long)c->npairs * c->nm * units;
-    const long target_groups = 256L * 16 * (64 / gw) * 4;
-    long ipg = total / target_groups;
-    if (ipg < 1) ipg = 1;
-    if (ipg > 8) ipg = 8;
-    return (int)ipg;
-}
-
-// items the node cache is indexed by: (pair, moment), or pairs alone in the shared EM layout
-long cache_items(const emme_ctx* c) { return (long)c->npairs * (c->em_shared ? 1 : c->nm); }
-// bytes of one part of the node cache in this context's record layout
-size_t cache_part_bytes(const emme_ctx* c, int gk_points, const NodeCacheGeom& g, int part) {
-    return c->tiled ? node_cache_bytes_tiled(c->npairs, g, part, gk_points) : node_cache_bytes(gk_points, cache_items(c), g, part);
-}
-hipError_t build_cache_part(emme_ctx* c, const AssembleLaunch& L, const NodeCacheGeom& g, int part, int cls, void* recs) {
-    const double omi = cls == 0 ? 1.0 : -1.0;
-    if (c->tiled) {
-        if (!c->d_tile_poison[cls]) {
-            const size_t ntiles = ((size_t)c->npairs + 15) / 16;
-            if (malloc_retry((void**)&c->d_tile_poison[cls], ntiles) != hipSuccess) return hipErrorOutOfMemory;
-            const hipError_t e = hipMemsetAsync(c->d_tile_poison[cls], 0, ntiles, c->stream);
-            if (e != hipSuccess) return e;
-        }
-        hipError_t e = launch_node_cache_tiled(L, g, part, omi, recs, c->d_ttab[cls], c->d_scale, c->stream, c->d_tile_poison[cls],
-                                               c->nm > 1 ? c->d_wtab[cls] : nullptr);
-        if (e == hipSuccess && std::getenv("EMME_DEBUG")) {
-            const size_t ntiles = ((size_t)c->npairs + 15) / 16;
-            std::vector<unsigned char> flags(ntiles);
-            (void)hipMemcpyAsync(flags.data(), c->d_tile_poison[cls], ntiles, hipMemcpyDeviceToHost, c->stream);
-            (void)hipStreamSynchronize(c->stream);
-            int n_poison = 0;
-            for (unsigned char f : flags) n_poison += f != 0;
-            fprintf(stderr, "[emme] node cache: class %d part %d built; tiles with a poisoned block so far: %d\n", cls, part, n_poison);
-        }
-        return e;
-    }
-    return launch_node_cache(L, g, part, omi, recs, c->d_ttab[cls], c->d_wtab[cls], c->d_scale, c->folded, c->stream);
-}
-
-// Make sure the main part of the node cache of contour class `cls` (0: omi=+1, 1: omi=-1)
-// exists.  Returns false (and disables the cache) if it does not fit the budget.
-bool ensure_node_cache(emme_ctx* c, const AssembleLaunch& L, int cls) {
-    if (c->cache_depth == -2) return false;
-    const double budget = c->opt.node_cache_gb * (double)(1 << 30);
-    if (c->cache_depth == -1) {
-        // full tree to depth dfull + the fixed subtree under the rightmost depth-5 node (that is
-        // where ordinary damped roots refine); the largest that leaves half the budget free
-        static const int options[][3] = {{8, 5, 13}, {7, 5, 13}, {6, 5, 13}, {6, 5, 12}, {6, 5, 11},
-                                         {5, 4, 10}, {5, 4, 9},  {4, 3, 7},  {3, 2, 5}};
-        // A cache that reaches less deep than depth 5 sends most integrals of a damped omega to the
-        // from-scratch kernel and is SLOWER than no cache at all (measured, N = 1024, where only depth 4
-        // fits: 83 omega-points/s with that cache against 335 through the omega-lane kernel,
-        // profiles/r02_size_sweep.jsonl): below that the context runs uncached (EMME_CACHE_MIN_DEPTH)
-        // (tiled contexts: 6 -- their records are a third smaller, so depth 5 does fit at N = 1024, and is
-        // as bad there: 97 omega-points/s)
-        const int min_depth = c->opt.cache_min_depth > 0 ? c->opt.cache_min_depth : (c->tiled ? 6 : 5);
-        bool found = false;
-        for (const auto& o : options) {
-            if (o[0] < min_depth) break;
-            NodeCacheGeom g{};
-            g.dfull = o[0], g.nsub = 1, g.rd[0] = o[1], g.dd[0] = o[2], g.rp[0] = (1ull << o[1]) - 1ull;
-            if ((double)cache_part_bytes(c, L.gk_points, g, -1) <= 0.25 * budget) {
-                c->cache_geom = g;
-                found = true;
-                break;
-            }
-        }
-        if (!found) {
-            c->cache_depth = -2;
-            return false;
-        }
-        c->cache_depth = c->cache_geom.dfull;
-        c->cache_max_intervals = node_cache_intervals(c->cache_geom) + (NODE_CACHE_MAX_SUB - 1) * 511;
-    }
-    if (c->d_recs[cls]) return true;
-    const size_t bytes = cache_part_bytes(c, L.gk_points, c->cache_geom, -1);
-    AllocTimer at(c);
-    if (c->cache_bytes_used + (double)bytes > budget ||
-        pool_alloc(&c->d_recs[cls], bytes, c->device) != hipSuccess ||
-        malloc_retry(&c->d_ttab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess ||
-        ((c->em_shared || (c->tiled && c->nm > 1)) &&
-         malloc_retry(&c->d_wtab[cls], node_ttab_bytes(L.gk_points, c->cache_max_intervals)) != hipSuccess) ||
-        (!c->d_scale &&
-         malloc_retry((void**)&c->d_scale, sizeof(double) * c->cache_max_intervals) != hipSuccess)) {
-        (void)hipGetLastError();
-        pool_free(c->d_recs[cls], bytes, c->device);
-        c->d_recs[cls] = nullptr;
-        c->cache_depth = -2;  // fall back to the on-the-fly kernels for good
-        return false;
-    }
-    at.stop();
-    c->cache_bytes_used += (double)bytes;
-    c->recs_bytes[cls] = bytes;
-    ScopedSpan s(c, K_CACHE);
-    if (build_cache_part(c, L, c->cache_geom, -1, cls, c->d_recs[cls]) != hipSuccess) {
-        c->cache_depth = -2;
-        return false;
-    }
-    return true;
-}
-
-// Which registered subtree covers interval (depth, path)?  -1 if none.
-int find_subtree(const NodeCacheGeom& g, int depth, unsigned long long path) {
-    for (int k = 0; k < g.nsub; ++k)
-        if (depth >= g.rd[k] && depth <= g.dd[k] && (path >> (depth - g.rd[k])) == g.rp[k]) return k;
-    return -1;
-}
-
-// The previous cached fill deferred integrals of contour class `cls` because interval
-// (depth, path) was not cached for that class: build the subtree that covers it for this class,
-// registering a new one around it (root 4 levels up, 8 levels deep = 511 intervals) if none does.
-// Subtrees are built per class, on demand: the few omegas on the other side of the imaginary
-// axis do not get 12 GB copies of regions they never visit.  Failure is harmless: those
-// integrals keep going through the work list.
-void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned long long path, int cls) {
-    NodeCacheGeom& g = c->cache_geom;
-    if (c->ext_failed || !c->d_recs[cls]) return;
-    if (depth <= g.dfull) return;  // (inside the full tree: a poisoned tile's hand-over, not a missing interval)
-    int k = find_subtree(g, depth, path);
-    const bool fresh = k < 0;
-    if (k == 0) return;  // the fixed subtree lives in the main buffer: nothing to add
-    if (fresh) {
-        if (g.nsub >= NODE_CACHE_MAX_SUB) return;
-        const int rd = depth - 4 < 1 ? 1 : depth - 4;
-        k = g.nsub;
-        g.rd[k] = rd;
-        g.rp[k] = path >> (depth - rd);
-        g.dd[k] = rd + 8;
-        g.nsub = k + 1;
-    } else if (c->d_recs_ext[cls][k - 1]) {
-        return;  // already there (the deferral was for an interval deeper than the subtree)
-    }
-    const double budget = c->opt.node_cache_gb * (double)(1 << 30);
-    const size_t eb = cache_part_bytes(c, L.gk_points, g, k - 1);
-    AllocTimer at(c);
-    if (c->cache_bytes_used + (double)eb > budget ||
-        pool_alloc(&c->d_recs_ext[cls][k - 1], eb, c->device) != hipSuccess) {
-        (void)hipGetLastError();
-        c->d_recs_ext[cls][k - 1] = nullptr;
-        c->ext_failed = true;
-        if (fresh) g.nsub = k;  // nothing built: forget the registration
-        return;
-    }
-    at.stop();
-    c->cache_bytes_used += (double)eb;
-    c->recs_ext_bytes[cls][k - 1] = eb;
-    {
-        ScopedSpan s(c, K_CACHE);
-        if (build_cache_part(c, L, g, k - 1, cls, c->d_recs_ext[cls][k - 1]) != hipSuccess) c->ext_failed = true;
-    }
-    if (std::getenv("EMME_DEBUG"))
-        fprintf(stderr, "[emme] node cache: subtree %d (depth %d path %llx, to depth %d) built for class %d, %.1f GiB in use\n",
-                k, g.rd[k], g.rp[k], g.dd[k], cls, c->cache_bytes_used / (double)(1 << 30));
-}
-
-// host_active: which of the nbatch items to assemble (null = all).  Batches of wl_min or
-// more items go through the omega-lane kernel, which shares the omega-independent node
-// data between items; smaller ones through the lanes-are-nodes kernel.
-int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
-                const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
-                const double* d_domega, const unsigned long long* cost = nullptr,
-                const double* host_omega = nullptr, bool newton_loop = false) {
-    AssembleLaunch L;
-    L.P = c->P;
-    L.gk_points = c->p.integration_start_points;
-    L.nbatch = nbatch;
-    L.npairs = c->npairs;
-    L.tab = c->d_tab;
-    L.pairs = c->d_pairs;
-    L.omega = d_omega;
-    L.active = d_active;
-    L.M = d_M;
-    L.Mold = d_Mold;
-    L.Mp = d_Mp;
-    L.domega = d_domega;
-    L.intervals = c->d_intervals;
-    L.status = c->d_status;
-    L.rounds = c->d_rounds;
-    // inside a root search a matrix that already holds a non-finite integral is lost (k_newton_update retires its
-    // chain): the fill kernels leave it alone.  Plain assembly calls always get the whole matrix.
-    L.skip_lost = newton_loop && c->opt.skip_lost != 0;
-    L.union_sel = c->opt.union_sel;
-    L.union_walk = c->opt.fill != EMME_FILL_LANES;
-    L.coop_wide_min = c->opt.coop_wide_min;
-    L.defer_one_group = c->opt.defer_one_group;
-    L.dense_min_cols = c->opt.dense_min_cols;
-    std::vector<int>& idx = c->h_actidx;
-    idx.clear();
-    for (int b = 0; b < nbatch; ++b)
-        if (!host_active || host_active[b] != 0) idx.push_back(b);
-    const int n_act = (int)idx.size();
-    if (n_act == 0) return EMME_OK;
-    // Items that share a lane group walk the union of their quadrature trees, so a cheap
-    // item next to an expensive one costs as much as the expensive one: group items of
-    // similar cost (interval count of their previous assembly) together.
-    if (cost)
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    // omegas whose level lists overflowed in their previous fill (root search only): first, a chunk each, through the
-    // wide-list build of the dense fill
-    int n_wide = 0;
-    if (newton_loop && c->tiled && c->nm == 1 && !c->h_wide.empty()) {
-        std::stable_partition(idx.begin(), idx.end(), [&](int b) { return c->h_wide[b] != 0; });
-        for (int b : idx) n_wide += c->h_wide[b] != 0;
-    }
-    // contour classes present among the omegas (needs their host values)
-    // The cache costs a few hundred ms of kernels plus the allocation of up to ~170 GB to build
-    // and pays off after ~10 fills: a call with a handful of omegas (a single root of a
-    // parameter scan) goes through the on-the-fly kernels unless the cache already exists.
-    bool use_cache = host_omega != nullptr && c->cache_depth != -2 &&
-                     (nbatch >= c->opt.cache_min_batch || c->d_recs[0] != nullptr || c->d_recs[1] != nullptr);
-    if (use_cache) {
-        bool need[2] = {false, false};
-        for (int b : idx) need[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1] = true;
-        for (int k = 0; k < 2 && use_cache; ++k)
-            if (need[k]) use_cache = ensure_node_cache(c, L, k);
-        // the previous cached fill deferred a sizeable share of its integrals: look at which
-        // intervals they were missing and cache a subtree around the most frequent one(s)
-        if (use_cache && c->d_worklist_count && c->d_defer_info) {
-            if (!c->pub_valid) {  // (the Newton loop gets the count from k_retire through pinned memory)
-                HIP_TRY(hipMemcpyAsync(&c->last_deferred, c->d_worklist_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-            }
-            c->pub_valid = false;
-            if (c->last_deferred >= 32) {
-                const size_t cnt = std::min<size_t>(c->last_deferred, 1u << 16);
-                std::vector<unsigned long long> info(cnt);
-                HIP_TRY(hipMemcpy(info.data(), c->d_defer_info, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                std::sort(info.begin(), info.end());
-                // most frequent missing interval per contour class (bit 55 of an entry)
-                unsigned long long best[2] = {0, 0};
-                size_t best_n[2] = {0, 0}, total[2] = {0, 0};
-                for (size_t q = 0; q < cnt;) {
-                    size_t e = q;
-                    while (e < cnt && info[e] == info[q]) ++e;
-                    const int k = (int)((info[q] >> 55) & 1ull);
-                    total[k] += e - q;
-                    if (e - q > best_n[k]) best_n[k] = e - q, best[k] = info[q];
-                    q = e;
-                }
-                if (std::getenv("EMME_DEBUG"))
-                    for (int k = 0; k < 2; ++k)
-                        if (total[k])
-                            fprintf(stderr, "[emme] deferrals of class %d: %zu, most frequent missing interval depth %d path %llx (%zu)\n", k,
-                                    total[k], (int)(best[k] >> 56), best[k] & 0x7fffffffffffffull, best_n[k]);
-                for (int k = 0; k < 2; ++k)
-                    if (total[k] >= 32 && best_n[k] * 4 >= total[k])
-                        add_cache_subtree(c, L, (int)(best[k] >> 56), best[k] & 0x7fffffffffffffull, k);
-            }
-        }
-    }
-    if (use_cache) {
-        // work list for integrals that outgrow the cache (worst case: every one of them)
-        const size_t need = (size_t)c->npairs * c->nm * (size_t)nbatch;
-        if (need > c->worklist_cap) {
-            if (c->d_worklist) (void)hipFree(c->d_worklist);
-            c->d_worklist = nullptr;
-            HIP_TRY(malloc_retry((void**)&c->d_worklist, need * sizeof(unsigned long long)));
-            if (c->d_defer_info) (void)hipFree(c->d_defer_info);
-            c->d_defer_info = nullptr;
-            HIP_TRY(malloc_retry((void**)&c->d_defer_info, need * sizeof(unsigned long long)));
-            c->worklist_cap = need;
-        }
-        if (!c->d_worklist_count) HIP_TRY(malloc_retry((void**)&c->d_worklist_count, sizeof(unsigned int)));
-
-    }
-    if (use_cache) {
-        const int gw = L.gk_points == 15 ? 16 : 32;
-        // the union-walk kernel (electrostatic GK15 on folded records, assemble_cached.hip): lanes
-        // that sit a round out cost little there, so its chunks are always full and each group
-        // takes three items (measured optimum: 86.5 ms vs 104 with the policy below)
-        const bool union_walk = (c->opt.fill != EMME_FILL_LANES || c->tiled) && c->folded && c->nm == 1 && L.gk_points == 15;
-        // Omega chunks of unequal size.  Every lane walks ONE omega's trees, so an
-        // omega whose integrals need 3x the intervals keeps its lane busy 3x longer than its
-        // neighbours'.  A chunk of n omegas gives each of them gw/n lanes per group: expensive
-        // omegas go into small chunks, cheap ones share a chunk 16 (32) at a time.  idx is
-        // sorted by cost, most expensive first, so chunk capacities only grow along the list.
-        std::vector<int>& ch = c->h_chunks;
-        ch.clear();
-        if (!idx.empty()) {
-            std::vector<unsigned long long> cs;
-            for (int b : idx) cs.push_back(cost ? cost[b] : 1ull);
-            std::vector<unsigned long long> sorted = cs;
-            std::sort(sorted.begin(), sorted.end());
-            const double typical = (double)std::max<unsigned long long>(sorted[sorted.size() / 2], 1ull);
-            // dense fill: one wave walks a (16-pair tile, chunk) serially, so (a) a chunk of omegas whose
-            // trees do not overlap costs the SUM of their walks in one wave -- expensive omegas get narrow
-            // chunks like in the independent-lane kernels -- and (b) a launch needs several times more
-            // tile tasks than the chip holds waves: the widest chunk shrinks until there are at least
-            // EMME_DENSE_MIN_TASKS (2000; 8000 while every lane ended with a global atomic -- with the counters
-            // summed per workgroup 0 .. 3000 are equal, 44.7 ms of fill per bench search, and 8000 costs 45.8)
-            // (dense fill: a chunk is 16 COLUMNS -- 16 omegas, or 5 omegas x 3 moments)
-            const int tile_cap = 16 / c->nm;
-            int dense_cap = c->tiled ? tile_cap : gw;
-            if (c->tiled) {
-                const long ntiles = (c->npairs + 15) / 16;
-                const long min_tasks = c->opt.dense_min_tasks;
-                while (dense_cap > 2 && ((long)idx.size() + dense_cap - 1) / dense_cap * ntiles < min_tasks) dense_cap >>= 1;
-            }
-            const double dense_ratio = c->opt.dense_cost_ratio;
-            size_t q = 0;
-            for (; q < (size_t)n_wide; ++q) ch.push_back((int)q), ch.push_back(1);
-            while (q < idx.size()) {
-                int cap = c->tiled ? dense_cap : gw;
-                while ((!union_walk || c->tiled) && cap > (c->tiled ? 2 : 1) &&
-                       (double)cs[q] * cap > typical * (c->tiled ? tile_cap * dense_ratio : gw * 1.5))
-                    cap >>= 1;
-                const int n = (int)std::min<size_t>((size_t)cap, idx.size() - q);
-                ch.push_back((int)q);
-                ch.push_back(n);
-                q += (size_t)n;
-            }
-        }
-        const int nchunks = (int)ch.size() / 2;
-        const int n_lane = (int)idx.size();
-        L.items_per_group = union_walk ? 3 : items_per_group_for(c, nchunks > 0 ? nchunks : 1);
-        if (union_walk) {
-            // up to three chunks (late Newton steps: <= 48 omegas) leave the SIMDs short of waves
-            // with three items per group: two then (measured: one is worse again -- every
-            // workgroup stages the grid tables; EMME_UNION_IPG_FEW / EMME_UNION_FEW_CHUNKS)
-            const int ipg_few = c->opt.union_ipg_few, few = c->opt.union_few_chunks;
-            if (nchunks <= few) L.items_per_group = std::max(1, ipg_few);
-        }
-        if (n_lane) {
-            // omega order | chunk table: into a pinned slot, then ONE small kernel moves both to the device
-            int* slot = c->p_lists + (size_t)(c->p_lists_turn++ & 1u) * c->p_lists_cap;
-            std::copy(idx.begin(), idx.end(), slot);
-            std::copy(ch.begin(), ch.end(), slot + n_lane);
-            int n2 = (int)ch.size();
-            if (c->tiled) {  // dense fill: position -> (chunk, column) map behind the chunk table
-                for (int k = 0; k < nchunks; ++k)
-                    for (int w = 0; w < ch[2 * k + 1]; ++w) slot[n_lane + n2 + ch[2 * k] + w] = (k << 8) | w;
-                n2 += n_lane;
-            }
-            HIP_TRY(launch_stage_ints(slot, c->d_actidx, n_lane, c->d_chunks, n2, c->stream));
-        }
-        HIP_TRY(hipMemsetAsync(c->d_worklist_count, 0, sizeof(unsigned int), c->stream));
-        c->last_fill_mode = c->tiled ? 4 : (union_walk ? 3 : 2);
-        if (n_lane && c->tiled) {
-            // dense fill: weighted phase tables for every cached interval and omega chunk, then one wave
-            // per (16-pair tile, 16-omega chunk); chunk c = positions 16 c .. of the cost-sorted list
-            const int n_int = node_cache_intervals(c->cache_geom);
-            const int nch = nchunks;
-            const size_t need = btab_bytes(n_int, nch, L.gk_points);
-            if (need > c->btab_cap) {
-                if (c->d_btab) (void)hipFree(c->d_btab);
-                c->d_btab = nullptr, c->btab_cap = 0;
-                HIP_TRY(malloc_retry(&c->d_btab, need + need / 4));
-                c->btab_cap = need + need / 4;
-            }
-            {
-                ScopedSpan s(c, K_OTHER);
-                HIP_TRY(launch_btab(L.gk_points, c->nm, n_int, c->d_ttab, c->d_wtab, d_omega, c->d_actidx, n_lane,
-                                    c->d_chunks + 2 * nchunks, nchunks, c->d_btab, c->stream));
-            }
-            {
-                ScopedSpan s(c, K_ASM);
-                static const bool stamps = std::getenv("EMME_DEBUG_STAMPS") != nullptr;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                unsigned long long r0[16] = {};
-                if (stamps) {  // diagnostic (EMME_DENSE_STAMPS build): this launch's tasks, their total and longest time
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                    HIP_TRY(hipMemcpy(r0, c->d_rounds, sizeof r0, hipMemcpyDeviceToHost));
-                    const unsigned long long zero = 0;
-                    HIP_TRY(hipMemcpy(c->d_rounds + 9, &zero, sizeof zero, hipMemcpyHostToDevice));
-                    HIP_TRY(hipEventCreate(&e0));
-                    HIP_TRY(hipEventCreate(&e1));
-                    HIP_TRY(hipEventRecord(e0, c->stream));
-                }
-                HIP_TRY(launch_assemble_dense(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_scale, c->d_btab,
-                                              c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx, n_lane,
-                                              c->d_chunks, nchunks, c->d_rounds, c->stream, c->d_tile_poison,
-                                              (c->opt.dense_wide && c->nm == 1) ? nchunks : n_wide, newton_loop ? c->d_overflow : nullptr));
-                if (stamps) {
-                    HIP_TRY(hipEventRecord(e1, c->stream));
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                    float ms = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-                    unsigned long long r1[16] = {};
-                    HIP_TRY(hipMemcpy(r1, c->d_rounds, sizeof r1, hipMemcpyDeviceToHost));
-                    const double tasks = (double)(r1[3] - r0[3]), tot = (double)(r1[8] - r0[8]);
-                    fprintf(stderr, "[emme] dense launch: %d omegas in %d chunks, %.0f tasks, %.3f ms; task ticks: mean %.0f, longest %.0f, "
-                            "sum / 2048 wave slots %.0f; rounds dense %llu sparse %llu\n", n_lane, nchunks, tasks, ms,
-                            tasks > 0 ? tot / tasks : 0.0, (double)r1[9], tot / 2048.0, r1[0] - r0[0], r1[1] - r0[1]);
-                    {   // how the tiles' times are spread (all chunks of the launch added up per tile)
-                        const size_t nt = std::min<size_t>(((size_t)c->npairs + 15) / 16, 8192);
-                        std::vector<unsigned long long> tt(nt);
-                        HIP_TRY(hipMemcpy(tt.data(), c->d_rounds + 16, nt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                        HIP_TRY(hipMemset(c->d_rounds + 16, 0, nt * sizeof(unsigned long long)));
-                        // first, middle and last tiles in index order, then percentiles
-                        fprintf(stderr, "[emme]   tile ticks by index: %llu %llu %llu %llu %llu | ", tt[0], tt[nt / 4], tt[nt / 2], tt[3 * nt / 4], tt[nt - 1]);
-                        std::sort(tt.begin(), tt.end());
-                        fprintf(stderr, "sorted: min %llu p25 %llu p50 %llu p75 %llu p90 %llu p97 %llu max %llu\n", tt[0], tt[nt / 4], tt[nt / 2],
-                                tt[3 * nt / 4], tt[nt * 9 / 10], tt[nt * 97 / 100], tt[nt - 1]);
-                    }
-                    (void)hipEventDestroy(e0);
-                    (void)hipEventDestroy(e1);
-                }
-            }
-        } else if (n_lane && c->folded) {
-            // phase table of this launch: exp(T omega) for every cached interval, node and omega
-            const int n_int = node_cache_intervals(c->cache_geom);
-            const size_t need = (size_t)n_lane * n_int * gw * 2 * sizeof(double);
-            if (need > c->etab_bytes) {
-                if (c->d_etab) (void)hipFree(c->d_etab);
-                c->d_etab = nullptr, c->etab_bytes = 0;
-                HIP_TRY(malloc_retry(&c->d_etab, need + need / 4));
-                c->etab_bytes = need + need / 4;
-            }
-            ScopedSpan s(c, K_OTHER);
-            HIP_TRY(launch_phase_table(L.gk_points, n_int, c->d_ttab, d_omega, c->d_actidx, n_lane, c->d_etab,
-                                       c->stream));
-        }
-        if (n_lane && !c->tiled) {
-            ScopedSpan s(c, K_ASM);
-            const void* etab = c->folded ? c->d_etab : nullptr;
-            if (c->em_shared)
-                HIP_TRY(launch_assemble_cached_em(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_wtab,
-                                                  c->d_scale, etab, c->d_worklist, c->d_worklist_count, c->d_defer_info,
-                                                  c->d_actidx, n_lane, c->d_chunks, nchunks, c->stream));
-            else
-                HIP_TRY(launch_assemble_cached(L, c->cache_geom, c->d_recs, c->d_recs_ext, c->d_ttab, c->d_scale, etab,
-                                               c->d_worklist, c->d_worklist_count, c->d_defer_info, c->d_actidx,
-                                               n_lane, c->d_chunks, nchunks, c->stream));
-        }
-        if (n_lane) {
-            ScopedSpan s(c, K_DEFER);
-            // (tiled electromagnetic contexts: the cooperative kernel does not read 32-slot tile blocks -- the few
-            // integrals that leave the cache are evaluated from scratch)
-            const bool coop_cached = !(c->tiled && c->nm > 1);
-            HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, coop_cached ? &c->cache_geom : nullptr, c->d_recs,
-                                         c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream,
-                                         c->tiled && coop_cached, c->d_tile_poison));
-        }
-        if (std::getenv("EMME_DEBUG")) {
-            unsigned int cnt = 0;
-            (void)hipMemcpy(&cnt, c->d_worklist_count, sizeof cnt, hipMemcpyDeviceToHost);
-            std::vector<unsigned long long> wl(cnt < 8 ? cnt : 8);
-            if (!wl.empty()) (void)hipMemcpy(wl.data(), c->d_worklist, wl.size() * 8, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[emme] cached fill: %d items, %u integrals deferred (of %ld)", n_act, cnt,
-                    (long)c->npairs * c->nm * n_act);
-            std::vector<unsigned long long> dg(wl.size());
-            if (!wl.empty() && c->d_defer_info) (void)hipMemcpy(dg.data(), c->d_defer_info, wl.size() * 8, hipMemcpyDeviceToHost);
-            for (size_t q = 0; q < wl.size(); ++q)
-                fprintf(stderr, " b%llu:i%llu@d%llu:p%llx", wl[q] >> 32, wl[q] & 0xffffffffull, dg[q] >> 56,
-                        dg[q] & 0x7fffffffffffffull);
-            fprintf(stderr, "\n");
-        }
-    } else if (n_act >= c->opt.wl_min) {
-        const int gw = L.gk_points == 15 ? 16 : 32;
-        L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
-        {
-            int* slot = c->p_lists + (size_t)(c->p_lists_turn++ & 1u) * c->p_lists_cap;
-            std::copy(idx.begin(), idx.end(), slot);
-            HIP_TRY(launch_stage_ints(slot, c->d_actidx, n_act, nullptr, 0, c->stream));
-        }
-        c->last_fill_mode = 1;
-        ScopedSpan s(c, K_ASM);
-        HIP_TRY(launch_assemble_wl(L, c->d_actidx, n_act, c->stream));
-    } else {
-        L.items_per_group = items_per_group_for(c, nbatch);
-        c->last_fill_mode = 0;
-        ScopedSpan s(c, K_ASM);
-        HIP_TRY(launch_assemble(L, c->stream));
-    }
-    c->acc.matrices += n_act;
-    return EMME_OK;
-}
-
 }  // namespace
+
 
 extern "C" {
 
