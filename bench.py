@@ -642,6 +642,10 @@ def main():
                 lu_main["avg_launch_ms"] = prof.linstep_ms / max(prof.linstep_launches, 1)
                 lu_main["launches"] = prof.linstep_launches
                 lu_main["pmc_summary"] = roof.get("pmc_summary")
+                # (per LAUNCH, like the fill's block: the step's LU launches are equal work -- K fixed steps, all chains live)
+                lu_main["traffic_per_step"] = lu_r["traffic"]
+                lu_main["traffic"] = lu_r["traffic"] / max(lu_r["launches_per_step"], 1e-9)
+                lu_main["fp64_flop_issued_per_launch"] = lu_r["fp64_flop_issued_per_step"] / max(lu_r["launches_per_step"], 1e-9)
                 out["roofline_fill"] = roof
                 out["roofline"] = lu_main
             # configs[4] builds a fresh node cache per k_rho INSIDE the timed region: there the record builder is the
