@@ -140,7 +140,7 @@ void add_cache_subtree(emme_ctx* c, const AssembleLaunch& L, int depth, unsigned
 int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
                 const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
                 const double* d_domega, const unsigned long long* cost = nullptr,
-                const double* host_omega = nullptr, bool newton_loop = false);
+                const double* host_omega = nullptr, bool newton_loop = false, bool force_uncached = false);
 
 // ---- emme_capi.hip ----------------------------------------------------------------------------------------
 hipEvent_t get_event(emme_ctx* c);

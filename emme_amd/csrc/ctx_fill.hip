@@ -25,7 +25,8 @@ int items_per_group_for(const emme_ctx* c, long units) {
 // data between items; smaller ones through the lanes-are-nodes kernel.
 int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_active,
                 const int* host_active, double* d_M, const double* d_Mold, double* d_Mp,
-                const double* d_domega, const unsigned long long* cost, const double* host_omega, bool newton_loop) {
+                const double* d_domega, const unsigned long long* cost, const double* host_omega, bool newton_loop,
+                bool force_uncached) {
     AssembleLaunch L;
     L.P = c->P;
     L.gk_points = c->p.integration_start_points;
@@ -72,11 +73,33 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
     // The cache costs a few hundred ms of kernels plus the allocation of up to ~170 GB to build
     // and pays off after ~10 fills: a call with a handful of omegas (a single root of a
     // parameter scan) goes through the on-the-fly kernels unless the cache already exists.
-    bool use_cache = host_omega != nullptr && c->cache_depth != -2 &&
+    bool use_cache = !force_uncached && host_omega != nullptr && c->cache_depth != -2 &&
                      (nbatch >= c->opt.cache_min_batch || c->d_recs[0] != nullptr || c->d_recs[1] != nullptr);
     if (use_cache) {
         bool need[2] = {false, false};
-        for (int b : idx) need[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1] = true;
+        int count[2] = {0, 0};
+        for (int b : idx) ++count[-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1];
+        need[0] = count[0] > 0, need[1] = count[1] > 0;
+        // A contour class that holds only a few of the call's omegas and has no cache yet does not get one for their
+        // sake: its main part costs as much to build as for a full batch (N = 512: 32 ms, and another 32 for the first
+        // subtree), while those few omegas cost 0.7 ms each through the uncached kernel -- a context that lives for
+        // one root search (BASELINE configs[4]: a fresh one per k_rho, one or two of 32 chains on the Re omega > 0
+        // side) never earns it back.  The minority goes through the omega-lane kernel in a second pass of this call;
+        // once it is more than a sixteenth of the batch its cache is built as before.
+        for (int k = 0; k < 2; ++k) {
+            if (need[0] && need[1] && !c->d_recs[k] && count[k] * 16 <= n_act && count[k] < count[1 - k]) {
+                std::vector<int> major(nbatch, 0), minor(nbatch, 0);
+                for (int b : idx) (((-std::copysign(1.0, host_omega[2 * b]) > 0.0 ? 0 : 1) == k) ? minor : major)[b] = 1;
+                int rc = do_assemble(c, nbatch, d_omega, d_active, major.data(), d_M, d_Mold, d_Mp, d_domega, cost, host_omega,
+                                     newton_loop, false);
+                if (rc) return rc;
+                const int mode = c->last_fill_mode;  // (the call's fill kernel, as reported, stays the majority's)
+                rc = do_assemble(c, nbatch, d_omega, d_active, minor.data(), d_M, d_Mold, d_Mp, d_domega, cost, host_omega,
+                                 newton_loop, true);
+                c->last_fill_mode = mode;
+                return rc;
+            }
+        }
         for (int k = 0; k < 2 && use_cache; ++k)
             if (need[k]) use_cache = ensure_node_cache(c, L, k);
         // the previous cached fill deferred a sizeable share of its integrals: look at which
@@ -311,7 +334,7 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
                         dg[q] & 0x7fffffffffffffull);
             fprintf(stderr, "\n");
         }
-    } else if (n_act >= c->opt.wl_min) {
+    } else if (n_act >= c->opt.wl_min || force_uncached) {
         const int gw = L.gk_points == 15 ? 16 : 32;
         L.items_per_group = items_per_group_for(c, (n_act + gw - 1) / gw);
         {

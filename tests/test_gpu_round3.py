@@ -377,3 +377,32 @@ def test_wide_level_lists_for_omegas_far_below_the_axis(emme, oracle):
         tol = max(TOL_M * np.abs(Mo).max(), 10.0 * noise)
         assert ivw[k] == tot
         assert np.abs(Mw[k] - Mo).max() <= tol and np.abs(Mn[k] - Mo).max() <= tol, (w, np.abs(Mw[k] - Mo).max(), tol)
+
+
+# ---- a contour class with only a few omegas does not get a cache of its own ----------------------------------
+def test_minority_contour_class_goes_uncached(emme, oracle):
+    """A batch whose Re omega > 0 side holds less than a sixteenth of the omegas, on a context without a cache for that
+    class: the majority goes through the cached (dense) fill, the minority through the omega-lane kernel in the same
+    call -- no cache is built for it (the context holds one class's buffers only), every matrix and interval count
+    equals the oracle's; when the minority grows its cache is built as before."""
+    d = example_tokamak(npoints=40)
+    po = oracle.params(d)
+    rng = np.random.default_rng(11)
+    ws = rng.uniform(-1.2, -0.4, 32) + 1j * rng.uniform(0.05, 0.4, 32)
+    ws[5] = 0.5 + 0.1j
+    ws[20] = 0.153 - 0.316j
+    with _ctx(emme, d, node_cache_gb=8.0) as ctx:
+        M, iv = ctx.assemble(ws, want_intervals=True)
+        assert ctx.fill_kernel().startswith("k_assemble_dense")
+        one = ctx.node_cache_gib()
+        M2, iv2 = ctx.assemble(ws, want_intervals=True)
+        assert ctx.node_cache_gib() == one and np.array_equal(iv, iv2)
+        # a quarter of the batch on the other side: now that class is cached too
+        ws3 = ws.copy()
+        ws3[:8] = 0.3 + 0.05j * np.arange(1, 9)
+        ctx.assemble(ws3)
+        assert ctx.node_cache_gib() > 1.5 * one
+    for k in (0, 5, 20, 31):
+        Mo, tot = oracle.assemble(po, complex(ws[k]))
+        assert iv[k] == tot, (k, ws[k], iv[k], tot)
+        assert np.abs(M[k] - Mo).max() <= TOL_M * np.abs(Mo).max(), (k, ws[k])
