@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 --pmc passes over one bench workload (tools/iter_profile.py: 2 root searches of the
+# rocprofv3 --pmc passes over one bench workload (tools/iter_profile.py 3: one preparing + three more root searches of the
 # 128-guess lattice) + the kernel trace of bench.py; run ON THE GPU BOX from the repo root:
 #   bash tools/pmc_collect.sh <tag> [config 3|4|5]  ->  gpurun_out/<tag>_pmc/pass*/..., gpurun_out/<tag>_pmc_summary.json,
 #                                            gpurun_out/<tag>_ktrace/..._kernel_stats.csv
@@ -23,10 +23,10 @@ passes=(
 i=0
 for p in "${passes[@]}"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d "$out/pass$i" -- python3 "$prog" 1 "$cfg" > "$out/pass$i.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d "$out/pass$i" -- python3 "$prog" 3 "$cfg" > "$out/pass$i.log" 2>&1
   rc=$?
   echo "pass $i ($p): rc $rc"
   if [ $rc -ge 124 ]; then echo "pass $i timed out: stopping"; exit 1; fi
 done
-python3 tools/pmc_summary.py "$out" "gpurun_out/${tag}_pmc_summary.json" 2 > "$out/summary.log" 2>&1
+python3 tools/pmc_summary.py "$out" "gpurun_out/${tag}_pmc_summary.json" 4 > "$out/summary.log" 2>&1
 tail -5 "$out/summary.log"
