@@ -1031,7 +1031,11 @@ int emme_null_vectors_batch(emme_ctx_t* c, int n, int nbatch, const double* M, d
     HIP_TRY(malloc_retry((void**)&t.v, sizeof(double) * 2 * (size_t)n * nbatch));
     HIP_TRY(malloc_retry((void**)&t.info, sizeof(int) * nbatch));
     const bool one_wg = trace_solve_blocked_lds(n) <= 150 * 1024;  // the whole L21 panel in one workgroup's LDS
-    const int max_sweeps = 60;  // (two at a converged root; the rest is for matrices that are not singular)
+    // two sweeps at a converged root; the rest is for matrices that are not singular (chains that never converged):
+    // a launch lasts as long as its slowest matrix, 0.18 ms per sweep at n = 256.  Measured on the 128 matrices of the
+    // headline search (worst 1 - overlap against the SVD where the SVD itself determines the vector): 60 sweeps
+    // 11.6 ms / 2.7e-14, 30 sweeps 6.7 ms / 8.9e-14, 20 sweeps 4.9 ms / 2.2e-9
+    const int max_sweeps = 30;
     if (one_wg || n <= 1024) {
         // blocked factorisations: row orders in the LU scratch.  Above the one-workgroup panel the chunked
         // multi-workgroup kernel of the Newton step factors (two workgroups per matrix, which must be resident
