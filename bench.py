@@ -341,11 +341,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    # The library's cold cost in a process that does NOT carry torch (the case of the reference's binary bound to the C
-    # ABI): tools/cold_probe.py as a child process, before this process touches the GPU.  (In THIS process the first
-    # search sometimes waits seconds inside one hipMalloc -- freshly leased boxes only, only under torch.cuda, whichever
-    # large allocation comes first at that moment; its cause is not established, DESIGN.md 8 -- so the in-process figure
-    # is reported too, as what it is.)
+    # The same cold call in a process that does NOT carry torch (the case of the reference's binary bound to the C ABI):
+    # tools/cold_probe.py as a child process, before this process touches the GPU.  (The driver's time inside hipMalloc
+    # -- node_cache_alloc_ms -- is 2 ms for the cache's 72 GiB most of the time and has been 1.4-6 s on freshly leased
+    # boxes, with and without torch; DESIGN.md 8.  Reporting both processes shows which part is whose.)
     cold_child = None
     if world == 1 and args.config == 3 and not args.no_cold and not args.npoints:
         import subprocess
@@ -448,11 +447,10 @@ def main():
                 "process_without_torch": cold_child,
                 "note": "first solve_roots on a FRESH context of THIS process (context creation, hipMalloc of the node "
                         "cache, its build kernels and cache growth included); the timed steps below run on the prepared "
-                        "context.  node_cache_alloc_ms is 2 ms for the 72 GiB on a box in use and has been seconds on "
-                        "freshly leased ones, under torch.cuda only (one hipMalloc of the process waits; cause not "
-                        "established).  process_without_torch = the same first search in a child process that does not "
-                        "carry torch (tools/cold_probe.py, run before this process touched the GPU): the library's own "
-                        "cold cost"}
+                        "context.  node_cache_alloc_ms = the driver's time inside hipMalloc for the cache's 72 GiB: 2 ms "
+                        "most of the time, 1.4-6 s on freshly leased boxes / right after other processes released the "
+                        "memory (cause not established, DESIGN.md 8).  process_without_torch = the same first search in a "
+                        "child process that never loads torch (tools/cold_probe.py, run before this process touched the GPU)"}
 
     class ProfSum:  # configs[4]: a context per k_rho -- their profiles added up
         FIELDS = [f[0] for f in emme_amd.Profile._fields_]
