@@ -29,4 +29,8 @@ if "--json" in sys.argv:  # (bench.py runs this file as a child process, before 
     import json
     print(json.dumps({"mode": mode, "context_create_s": t2 - t1, "first_search_s": t3 - t2, "node_cache_alloc_ms": pr.cache_alloc_ms,
                       "node_cache_build_ms": pr.cache_build_ms, "node_cache_gib": ctx.node_cache_gib(),
-                      "first_search_omega_points": int(iters[info == 0].sum()), "later_search_s": min(later)}))
+                      "first_search_omega_points": int(iters[info == 0].sum()), "later_search_s": min(later)}), flush=True)
+    # Leave WITHOUT giving the 72 GiB back call by call: the process that allocates right after one that hipFree'd tens of
+    # GiB waits seconds inside hipMalloc (tools/micro/bg_alloc_probe.py run in turns with this file: 3.8 s after this
+    # file's orderly exit, 2 ms after its own exit without frees) -- and that next process is the bench itself.
+    os._exit(0)
