@@ -425,7 +425,7 @@ class Context:
         o = self.options()
         folded = "true" if o.phase_table else "false"
         if mode == 4:
-            return "k_assemble_dense<1, 31, 3>" if em else "k_assemble_dense<1, 15, 1>"
+            return "k_assemble_dense<1, %d, %d>" % (pts, 3 if em else 1)
         if mode == 3:
             return "k_assemble_union<15, %d>" % o.union_sel
         if mode == 2:

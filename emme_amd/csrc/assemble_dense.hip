@@ -895,6 +895,10 @@ hipError_t launch_btab(int gk_points, int nm, int nslots, const void* const ttab
         hipLaunchKernelGGL((k_btab<15, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
     else if (gk_points == 31 && nm == 3)
         hipLaunchKernelGGL((k_btab<31, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    else if (gk_points == 15 && nm == 3)
+        hipLaunchKernelGGL((k_btab<15, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+    else if (gk_points == 31 && nm == 1)
+        hipLaunchKernelGGL((k_btab<31, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
     else
         return hipErrorNotSupported;
     return hipGetLastError();
@@ -944,11 +948,18 @@ hipError_t launch_assemble_dense(const AssembleLaunch& L, const NodeCacheGeom& g
     const int ntiles = (L.npairs + TILE_PAIRS - 1) / TILE_PAIRS;
     const int ntg = (ntiles + 3) / 4;
     const int nm = L.P.dim == L.P.N ? 1 : 3;
-    if (L.gk_points == 31 && nm == 3) {  // electromagnetic GK31 (64-entry level lists only; tile-major, XCD-aware order)
-        hipLaunchKernelGGL((k_assemble_dense<1, 31, 3>), dim3((unsigned)((long)((ntg + 7) / 8) * 8 * A.nchunks)), dim3(256), 0, stream, A);
+    if (nm == 3) {  // electromagnetic (64-entry level lists only; tile-major, XCD-aware order)
+        const dim3 grid((unsigned)((long)((ntg + 7) / 8) * 8 * A.nchunks));
+        if (L.gk_points == 31)
+            hipLaunchKernelGGL((k_assemble_dense<1, 31, 3>), grid, dim3(256), 0, stream, A);
+        else
+            hipLaunchKernelGGL((k_assemble_dense<1, 15, 3>), grid, dim3(256), 0, stream, A);
         return hipGetLastError();
     }
-    if (L.gk_points != 15 || nm != 1) return hipErrorNotSupported;
+    if (L.gk_points == 31) {  // electrostatic GK31 (64-entry level lists only)
+        hipLaunchKernelGGL((k_assemble_dense<1, 31, 1>), dim3((unsigned)((long)ntg * A.nchunks)), dim3(256), 0, stream, A);
+        return hipGetLastError();
+    }
     // the first n_wide chunks (omegas whose level lists overflowed last time) through the 128-entry build
     if (n_wide > A.nchunks) n_wide = A.nchunks;
     // (experiment, EMME_EXP_TILE_MAJOR = n: the electromagnetic task order for electrostatic launches of >= n chunks

@@ -313,9 +313,9 @@ int do_assemble(emme_ctx* c, int nbatch, const double* d_omega, const int* d_act
         }
         if (n_lane) {
             ScopedSpan s(c, K_DEFER);
-            // (tiled electromagnetic contexts: the cooperative kernel does not read 32-slot tile blocks -- the few
-            // integrals that leave the cache are evaluated from scratch)
-            const bool coop_cached = !(c->tiled && c->nm > 1);
+            // (tiled electromagnetic / GK31 contexts: the cooperative kernel reads the electrostatic GK15 tile blocks
+            // only -- the few integrals that leave the cache are evaluated from scratch)
+            const bool coop_cached = !(c->tiled && (c->nm > 1 || L.gk_points != 15));
             HIP_TRY(launch_assemble_list(L, c->d_worklist, c->d_worklist_count, coop_cached ? &c->cache_geom : nullptr, c->d_recs,
                                          c->d_recs_ext, c->d_ttab, c->em_shared ? c->d_wtab : nullptr, c->folded, c->stream,
                                          c->tiled && coop_cached, c->d_tile_poison));

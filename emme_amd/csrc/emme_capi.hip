@@ -46,12 +46,13 @@ namespace {
 
 size_t mat_doubles(const emme_ctx* c) { return (size_t)c->dim * c->dim * 2; }
 
-// Which contexts get the tiled record layout + dense (matrix-core) fill (assemble_dense.hip): electrostatic GK15 and
-// electromagnetic GK31 (the two shapes BASELINE.json's configurations use), on folded records, with the default fill
-// option.  The dense path carries the safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature
+// Which contexts get the tiled record layout + dense (matrix-core) fill (assemble_dense.hip): both quadrature orders,
+// electrostatic and electromagnetic (BASELINE.json's configurations use electrostatic GK15 and electromagnetic GK31),
+// on folded records, with the default fill option.  The dense path carries the safe_exp-clamped tails (<= 4e-14 absolute), so inputs whose absolute quadrature
 // goal (integration_accuracy) is tighter than 1e-9 keep the exact kernels.
 bool wants_tiled(const emme_params_t& p, bool es, bool folded, int fill) {
-    const bool shape = (es && p.integration_start_points == 15) || (!es && p.integration_start_points == 31);
+    const bool shape = p.integration_start_points == 15 || p.integration_start_points == 31;
+    (void)es;
     return shape && folded && p.integration_accuracy >= 1e-9 && fill == EMME_FILL_AUTO;
 }
 

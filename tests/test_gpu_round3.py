@@ -406,3 +406,25 @@ def test_minority_contour_class_goes_uncached(emme, oracle):
         Mo, tot = oracle.assemble(po, complex(ws[k]))
         assert iv[k] == tot, (k, ws[k], iv[k], tot)
         assert np.abs(M[k] - Mo).max() <= TOL_M * np.abs(Mo).max(), (k, ws[k])
+
+
+# ---- the dense fill serves both quadrature orders, electrostatic and electromagnetic ------------------------------
+@pytest.mark.parametrize("pts,em", [(15, False), (31, False), (15, True), (31, True)])
+def test_dense_fill_every_shape_matches_oracle(emme, oracle, pts, em):
+    """k_assemble_dense<1, PTS, NM> for PTS in {15, 31} x NM in {1, 3} (BASELINE's configurations use (15, 1) and
+    (31, 3)): the default path of every such context; matrices and interval counts against the oracle, both contour
+    classes, a damped omega included."""
+    from oracle.binding import example_stellarator
+    d = dict(example_stellarator(npoints=14), integration_start_points=pts) if em else example_tokamak(npoints=28, integration_start_points=pts)
+    po = oracle.params(d)
+    ws = np.array([-0.8 + 0.25j, -0.6 - 0.21j, 0.5 + 0.1j, -1.656 + 2.49j, 0.153 - 0.316j, -0.7 + 0.3j, -0.9 + 0.1j, -0.5 + 0.2j,
+                   -0.65 + 0.27j, -1.0 + 0.05j])
+    with _ctx(emme, d, node_cache_gb=8.0) as ctx:
+        M, iv = ctx.assemble(ws, want_intervals=True)
+        assert ctx.fill_kernel_symbol() == "k_assemble_dense<1, %d, %d>" % (pts, 3 if em else 1)
+        M2, iv2 = ctx.assemble(ws[3:5], want_intervals=True)
+    assert np.array_equal(iv2, iv[3:5])
+    for k, w in enumerate(ws):
+        Mo, tot = oracle.assemble(po, complex(w))
+        assert iv[k] == tot, (pts, em, w, iv[k], tot)
+        assert np.abs(M[k] - Mo).max() <= TOL_M * np.abs(Mo).max(), (pts, em, w)
